@@ -1,0 +1,82 @@
+"""ctypes binding of libbts_hip.so (C ABI declared in include/bts_hip.h).
+
+The product path has NO fallback: if the library is missing or a symbol is absent this
+module raises at import/first use, and every op raises on non-CUDA tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbts_hip.so")
+
+SYMBOLS = (
+    "bts_hip_abi_version", "bts_hip_error_string", "bts_lpg_fwd_f32", "bts_lpg_fused_fwd_f32",
+    "bts_reduc_fwd_f32", "bts_conv_fwd_f32", "bts_nchw_to_nhwc_f32", "bts_nhwc_to_nchw_f32",
+)
+
+ABI_VERSION = 1
+
+
+class ConvDesc(C.Structure):
+    """struct bts_conv_desc (include/bts_hip.h) -- field order and types must match."""
+    _fields_ = [
+        ("x", C.c_void_p), ("x_pix_stride", C.c_long), ("c_in_ld", C.c_int), ("k_pad", C.c_int),
+        ("B", C.c_int), ("h_in", C.c_int), ("w_in", C.c_int), ("up", C.c_int),
+        ("ksize", C.c_int), ("dil", C.c_int),
+        ("w", C.c_void_p), ("c_out", C.c_int), ("c_out_pad", C.c_int),
+        ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("pre_relu", C.c_int),
+        ("e1_scale", C.c_void_p), ("e1_shift", C.c_void_p), ("act", C.c_int),
+        ("e2_scale", C.c_void_p), ("e2_shift", C.c_void_p),
+        ("y", C.c_void_p), ("y_pix_stride", C.c_long), ("y_nchw", C.c_int),
+    ]
+
+
+class BtsHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BtsHipError(
+            "bts_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C bts_amd/csrc`; there is no CPU/PyTorch fallback for the hot path" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise BtsHipError("bts_amd: symbol %s missing from %s" % (s, LIB_PATH))
+    vp, i, l, f = C.c_void_p, C.c_int, C.c_long, C.c_float
+    lib.bts_hip_abi_version.restype = i
+    lib.bts_hip_abi_version.argtypes = []
+    lib.bts_hip_error_string.restype = C.c_char_p
+    lib.bts_hip_error_string.argtypes = [i]
+    lib.bts_lpg_fwd_f32.restype = i
+    lib.bts_lpg_fwd_f32.argtypes = [vp, i, i, i, i, vp, vp, vp]
+    lib.bts_lpg_fused_fwd_f32.restype = i
+    lib.bts_lpg_fused_fwd_f32.argtypes = [vp, i, i, i, i, i, f, vp, vp, i, l, vp, vp]
+    lib.bts_reduc_fwd_f32.restype = i
+    lib.bts_reduc_fwd_f32.argtypes = [vp, l, l, i, i, vp, l, f, i, i, vp, vp]
+    lib.bts_conv_fwd_f32.restype = i
+    lib.bts_conv_fwd_f32.argtypes = [C.POINTER(ConvDesc), vp]
+    lib.bts_nchw_to_nhwc_f32.restype = i
+    lib.bts_nchw_to_nhwc_f32.argtypes = [vp, i, i, l, vp, l, i, vp]
+    lib.bts_nhwc_to_nchw_f32.restype = i
+    lib.bts_nhwc_to_nchw_f32.argtypes = [vp, l, i, i, l, vp, vp]
+    if lib.bts_hip_abi_version() != ABI_VERSION:
+        raise BtsHipError("bts_amd: ABI version mismatch (%d != %d)" % (lib.bts_hip_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().bts_hip_error_string(code)
+        raise BtsHipError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))

@@ -1,0 +1,161 @@
+// Local planar guidance (LPG) forward for gfx950.
+//
+// Restates local_planar_guidance.forward (reference pytorch/bts.py:149-173) as ONE pass:
+// the reference materialises two repeat_interleave copies, CPU-built u/v grids (copied
+// H2D every call), ~20 elementwise passes and a min-reduction; here each thread produces
+// four adjacent output columns (one 16-byte store) straight from the 1/k-resolution plane
+// coefficients.  The op is HBM-write bound (4 B written per ~0.06-1 B read).
+//
+// Bit-exactness: den = (n1*u + n2*v) + n3 is evaluated with separately rounded mul/add (FMA
+// contraction disabled for this file), the clamp follows bts.py:168-171 and the divisions are
+// IEEE (hipcc's default correctly-rounded fp32 divide), so on identical inputs the result
+// equals the torch CPU reference bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+// hipcc defaults to -ffp-contract=fast, which would fuse n1*u + ... into FMAs and break bit-parity
+// with the reference's separately rounded mul/add kernels.  (HIP's __fmul_rn/__fadd_rn do NOT help:
+// they are header inlines compiled with the contract flag.)  This file is also built with
+// -ffp-contract=off (Makefile).
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float lpg_den(float n1, float n2, float n3, float u, float v) {
+    return (n1 * u + n2 * v) + n3;   // contraction is off for this file
+}
+
+__device__ __forceinline__ float lpg_clamp(float d) {
+    const float eps = 1e-3f;
+    if (d > 0.f && d < eps) d = eps;          // bts.py:170
+    if (d < 0.f && d > -eps) d = -eps;        // bts.py:171
+    return d;
+}
+
+// wave-min of |den| then one atomic per wave; abs(den) >= 0 so the uint order is the float order
+__device__ __forceinline__ void publish_abs_min(float m, unsigned* abs_min_bits) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMin(abs_min_bits, __float_as_uint(m));
+}
+
+// K = upratio (1,2,4,8).  PLANAR: input [B,4,h,w]; else cell-interleaved [B*h*w,4].
+// FUSED: optional normalize, divide by max_depth, strided nearest-downsample side output.
+template <int K, int V, bool PLANAR, bool FUSED>
+__global__ __launch_bounds__(256) void lpg_fwd_kernel(const float* __restrict__ plane, int B, int h, int w,
+                                                      int normalize, float max_depth,
+                                                      float* __restrict__ out, float* __restrict__ ds_out,
+                                                      int ds_factor, long ds_pix_stride,
+                                                      unsigned* __restrict__ abs_min_bits) {
+    const int W = w * K, H = h * K;
+    const int W4 = W / V;                        // V = 4 when W % 4 == 0 (16-byte stores), else 1
+    const long total = (long)B * H * W4;
+    float amin = __uint_as_float(0x7f800000u);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(t % W4);
+        const long rb = t / W4;
+        const int r = (int)(rb % H);
+        const int b = (int)(rb / H);
+        const int cr = r / K;
+        const float v = ((float)(r % K) - (float)(K - 1) * 0.5f) / (float)K;   // bts.py:160-161
+        float res[V];
+        constexpr int CELLS = (K >= V) ? 1 : (V / K);    // cells covered by V columns
+        constexpr int PER = V / CELLS;
+#pragma unroll
+        for (int ci = 0; ci < CELLS; ++ci) {
+            const int c0 = c4 * V + ci * PER;
+            const int cc = c0 / K;
+            float n1, n2, n3, n4;
+            if (PLANAR) {
+                const long hw = (long)h * w;
+                const float* p = plane + ((long)b * 4) * hw + (long)cr * w + cc;
+                n1 = p[0]; n2 = p[hw]; n3 = p[2 * hw]; n4 = p[3 * hw];
+            } else {
+                const float4 q = *reinterpret_cast<const float4*>(plane + (((long)b * h + cr) * w + cc) * 4);
+                n1 = q.x; n2 = q.y; n3 = q.z; n4 = q.w;
+            }
+            if (FUSED && normalize) {                       // F.normalize(p=2, dim=1, eps=1e-12), bts.py:251
+                const float nn = sqrtf((n1 * n1 + n2 * n2) + n3 * n3);
+                const float dn = fmaxf(nn, 1e-12f);
+                n1 = n1 / dn; n2 = n2 / dn; n3 = n3 / dn;
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = c0 + i;
+                const float u = ((float)(c % K) - (float)(K - 1) * 0.5f) / (float)K;  // bts.py:157-158
+                float d = lpg_den(n1, n2, n3, u, v);                                   // bts.py:166
+                amin = fminf(amin, fabsf(d));                                          // bts.py:167
+                d = lpg_clamp(d);
+                float y = n4 / d;                                                     // bts.py:173
+                if (FUSED) y = y / max_depth;                                         // bts.py:255
+                res[ci * PER + i] = y;
+            }
+        }
+        if constexpr (V == 4)
+            *reinterpret_cast<float4*>(out + ((long)b * H + r) * W + (long)c4 * 4) =
+                make_float4(res[0], res[1], res[2], res[3]);
+        else
+            out[((long)b * H + r) * W + c4] = res[0];
+        if (FUSED && ds_out != nullptr && (r % ds_factor) == 0) {   // nearest, scale 1/ds_factor == [::f, ::f]
+            const int Hd = H / ds_factor, Wd = W / ds_factor;
+            const long rowbase = ((long)b * Hd + r / ds_factor) * Wd;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const int c = c4 * V + i;
+                if ((c % ds_factor) == 0) ds_out[(rowbase + c / ds_factor) * ds_pix_stride] = res[i];
+            }
+        }
+    }
+    if (abs_min_bits != nullptr) publish_abs_min(amin, abs_min_bits);
+}
+
+template <bool PLANAR, bool FUSED>
+int launch_lpg(const float* plane, int B, int h, int w, int k, int normalize, float max_depth, float* out,
+               float* ds_out, int ds_factor, long ds_pix_stride, float* abs_min, hipStream_t s) {
+    if (!plane || !out || B <= 0 || h <= 0 || w <= 0) return BTS_ERR_INVALID;
+    if (k != 1 && k != 2 && k != 4 && k != 8) return BTS_ERR_UNSUPPORTED;
+    if (ds_out && (ds_factor <= 0 || (h * k) % ds_factor || (w * k) % ds_factor)) return BTS_ERR_INVALID;
+    if (FUSED && !(max_depth > 0.f)) return BTS_ERR_INVALID;
+    unsigned* bits = reinterpret_cast<unsigned*>(abs_min);
+    if (bits) {
+        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)bits, 0x7f800000, 1, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const bool vec4 = (((long)w * k) % 4) == 0;
+    const long total = (long)B * h * k * ((long)w * k / (vec4 ? 4 : 1));
+    long blocks = (total + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;      // grid-stride beyond 16 blocks/CU
+    dim3 grid((unsigned)blocks), block(256);
+#define LPG_LAUNCH(KK)                                                                                          \
+    if (vec4)                                                                                                   \
+        hipLaunchKernelGGL((lpg_fwd_kernel<KK, 4, PLANAR, FUSED>), grid, block, 0, s, plane, B, h, w, normalize, \
+                           max_depth, out, ds_out, ds_factor, ds_pix_stride, bits);                             \
+    else                                                                                                        \
+        hipLaunchKernelGGL((lpg_fwd_kernel<KK, 1, PLANAR, FUSED>), grid, block, 0, s, plane, B, h, w, normalize, \
+                           max_depth, out, ds_out, ds_factor, ds_pix_stride, bits)
+    switch (k) {
+        case 1: LPG_LAUNCH(1); break;
+        case 2: LPG_LAUNCH(2); break;
+        case 4: LPG_LAUNCH(4); break;
+        default: LPG_LAUNCH(8); break;
+    }
+#undef LPG_LAUNCH
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int bts_lpg_fwd_f32(const float* plane_eq, int B, int h, int w, int upratio, float* depth,
+                               float* abs_min, bts_stream_t stream) {
+    return launch_lpg<true, false>(plane_eq, B, h, w, upratio, 0, 1.f, depth, nullptr, 1, 0, abs_min,
+                                   (hipStream_t)stream);
+}
+
+extern "C" int bts_lpg_fused_fwd_f32(const float* plane4, int B, int h, int w, int upratio, int normalize,
+                                     float max_depth, float* depth_scaled, float* ds_out, int ds_factor,
+                                     long ds_pix_stride, float* abs_min, bts_stream_t stream) {
+    if (((uintptr_t)plane4 & 15) != 0) return BTS_ERR_INVALID;
+    return launch_lpg<false, true>(plane4, B, h, w, upratio, normalize, max_depth, depth_scaled, ds_out,
+                                   ds_factor, ds_pix_stride, abs_min, (hipStream_t)stream);
+}

@@ -1,0 +1,179 @@
+// reduction_1x1 forward for gfx950: the whole 1x1-conv(+ELU) chain of reference
+// pytorch/bts.py:97-136 in one kernel, activations never leaving registers.
+//
+// Mapping.  One wave owns a tile of 32 pixels.  Every layer is computed TRANSPOSED,
+// Y^T[Cout x 32px] = W[Cout x Cin] * X^T[Cin x 32px], on v_mfma_f32_32x32x2_f32 with the
+// weights as the A operand and the activations as the B operand.  The D tile then has the
+// pixel on the lane and the output channel in the register -- which is exactly the B-operand
+// shape of the next layer (register s of a D tile feeds MFMA k-step s), so a layer's output
+// (after ELU) is consumed by the next layer with no LDS round trip and no lane movement.
+// The k order this induces (lane half h, step s=4g+q  <->  channel 8g+4h+q) is baked into the
+// weight fragments, which the host packs once (bts_amd/ops.py:pack_reduc_weights) so that one
+// conflict-free lane-linear ds_read_b128 yields the A operands of four consecutive k-steps.
+// Weights live in LDS (<=114 KB for the 8x8 chain), copied once per workgroup.
+//
+// Roofline: 2x2 / 1x1 chains are HBM-read bound (AI 20 / 9.8 FLOP/B), 8x8 / 4x4 are (small)
+// MFMA-bound; see DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+namespace {
+
+// One dense layer: acc[mt] (32 out-rows each) = W * x, K real input channels (multiple of 8).
+// wf points at this layer's fragments: float4 index ((mt*(K/8) + g)*64 + lane).
+template <int K, int MT, int NX>
+__device__ __forceinline__ void dense_layer(const float4* __restrict__ wf, int lane, const float (&x)[NX],
+                                            f32x16 (&acc)[MT]) {
+    static_assert(NX >= K / 2, "activation registers");
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    // software-prefetch one g-step of weight fragments; the sched_barrier keeps hipcc from
+    // hoisting every ds_read of the layer to its top (which spills: 64 x b128 for 128->128)
+    float4 wn[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wn[mt] = wf[(mt * (K / 8)) * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < K / 8; ++g) {
+        float4 w[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) w[mt] = wn[mt];
+        if (g + 1 < K / 8) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) wn[mt] = wf[(mt * (K / 8) + g + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[mt] = mfma32x2(w[mt].x, x[4 * g + 0], acc[mt]);
+            acc[mt] = mfma32x2(w[mt].y, x[4 * g + 1], acc[mt]);
+            acc[mt] = mfma32x2(w[mt].z, x[4 * g + 2], acc[mt]);
+            acc[mt] = mfma32x2(w[mt].w, x[4 * g + 3], acc[mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Mirrors the while-loop of reduction_1x1.__init__ (bts.py:105-122): K = num_in_filters,
+// M = num_out_filters.  Leaves the last layer's first rows in o[0..2] (valid on lanes < 32).
+template <int K, int M, int NX>
+__device__ __forceinline__ void chain(const float4* __restrict__ wf, int lane, const float (&x)[NX], float (&o)[3]) {
+    if constexpr (M < 8) {                        // plane_params (3 outs) or final (1 out)
+        f32x16 acc[1];
+        dense_layer<K, 1, NX>(wf, lane, x, acc);
+        o[0] = acc[0][0]; o[1] = acc[0][1]; o[2] = acc[0][2];
+    } else {
+        constexpr int MT = (M + 31) / 32;
+        f32x16 acc[MT];
+        dense_layer<K, MT, NX>(wf, lane, x, acc);
+        constexpr int NY = (M / 2 < 4) ? 4 : M / 2;
+        float y[NY];
+#pragma unroll
+        for (int i = 0; i < NY; ++i) y[i] = elu1(acc[i / 16][i % 16]);      // conv + ELU, bts.py:116-119
+        chain<M, M / 2, NY>(wf + MT * (K / 8) * 64, lane, y, o);
+    }
+}
+
+template <int C0, int M0>
+constexpr long chain_frag_float4s() {
+    long n = 0;
+    int k = C0, m = M0;
+    while (m >= 8) { n += (long)((m + 31) / 32) * (k / 8) * 64; k = m; m = m / 2; }
+    n += (long)(k / 8) * 64;
+    return n;
+}
+
+template <int C0, int M0, bool FINAL>
+__global__ __launch_bounds__(512, 2) void reduc_fwd_kernel(const float* __restrict__ x, long x_pix_stride,
+                                                           long npix, const float4* __restrict__ w_frag,
+                                                           float max_depth, int normalize,
+                                                           float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float4* wl = reinterpret_cast<float4*>(smem_raw);
+    constexpr long NW = chain_frag_float4s<C0, M0>();
+    for (long i = threadIdx.x; i < NW; i += blockDim.x) wl[i] = w_frag[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long ntiles = (npix + 31) / 32;
+    for (long tile = (long)blockIdx.x * waves_per_block + wave; tile < ntiles;
+         tile += (long)gridDim.x * waves_per_block) {
+        const long p = tile * 32 + j;
+        const bool live = p < npix;
+        float xr[C0 / 2];
+        const float* xp = x + (live ? p : 0) * x_pix_stride + 4 * h;
+#pragma unroll
+        for (int t = 0; t < C0 / 8; ++t) {         // lane (j,h): channels 4*(2t+h) .. +3
+            float4 v = live ? *reinterpret_cast<const float4*>(xp + 8 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xr[4 * t + 0] = v.x; xr[4 * t + 1] = v.y; xr[4 * t + 2] = v.z; xr[4 * t + 3] = v.w;
+        }
+        float o[3];
+        chain<C0, M0, C0 / 2>(wl, lane, xr, o);
+        if (live && h == 0) {
+            if (FINAL) {
+                out[p] = sigmoid1(o[0]);                                        // bts.py:108-110
+            } else {
+                const float PI = 3.14159265358979323846f;
+                const float theta = sigmoid1(o[0]) * PI / 3.f;                  // bts.py:127
+                const float phi = sigmoid1(o[1]) * PI * 2.f;                    // bts.py:128
+                const float dist = sigmoid1(o[2]) * max_depth;                  // bts.py:129
+                float n1 = sinf(theta) * cosf(phi);                             // bts.py:130
+                float n2 = sinf(theta) * sinf(phi);                             // bts.py:131
+                float n3 = cosf(theta);                                         // bts.py:132
+                if (normalize) {                                                // bts.py:251
+                    const float nn = fmaxf(sqrtf(n1 * n1 + n2 * n2 + n3 * n3), 1e-12f);
+                    n1 /= nn; n2 /= nn; n3 /= nn;
+                }
+                *reinterpret_cast<float4*>(out + p * 4) = make_float4(n1, n2, n3, dist);
+            }
+        }
+    }
+}
+
+template <int C0, int M0, bool FINAL>
+int launch_reduc(const float* x, long stride, long npix, const float* w_frag, long w_frag_floats, float max_depth,
+                 int normalize, float* out, hipStream_t s) {
+    constexpr long NW = chain_frag_float4s<C0, M0>();
+    if (w_frag_floats != NW * 4) return BTS_ERR_INVALID;
+    const size_t lds = (size_t)NW * 16;
+    auto kern = reduc_fwd_kernel<C0, M0, FINAL>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long ntiles = (npix + 31) / 32;
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    long blocks = (ntiles + 7) / 8;
+    if (blocks > 256L * per_cu) blocks = 256L * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, x, stride, npix,
+                       reinterpret_cast<const float4*>(w_frag), max_depth, normalize, out);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int bts_reduc_fwd_f32(const float* x, long x_pix_stride, long npix, int c_in, int c_first_out,
+                                 const float* w_frag, long w_frag_floats, float max_depth, int is_final,
+                                 int normalize, float* out, bts_stream_t stream) {
+    if (!x || !w_frag || !out || npix <= 0) return BTS_ERR_INVALID;
+    if ((x_pix_stride & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w_frag & 15) || ((uintptr_t)out & 15))
+        return BTS_ERR_INVALID;
+    if (x_pix_stride < c_in) return BTS_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (!is_final) {
+        if (c_in == 128 && c_first_out == 128)
+            return launch_reduc<128, 128, false>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
+        if (c_in == 128 && c_first_out == 64)
+            return launch_reduc<128, 64, false>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
+        if (c_in == 64 && c_first_out == 32)
+            return launch_reduc<64, 32, false>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
+    } else {
+        if (c_in == 32 && c_first_out == 16)
+            return launch_reduc<32, 16, true>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
+    }
+    return BTS_ERR_UNSUPPORTED;
+}

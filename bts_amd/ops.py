@@ -1,0 +1,242 @@
+"""Host-side wrappers over the C ABI (include/bts_hip.h): argument validation, weight packing,
+stream plumbing.  torch is used only for device memory and the current stream.
+
+Every function requires CUDA(ROCm) fp32 tensors and raises otherwise -- no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BtsHipError, ConvDesc
+
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need(t: torch.Tensor, name: str):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise BtsHipError("bts_amd.%s: expected a CUDA/ROCm tensor (the hot path has no CPU fallback)" % name)
+    if t.dtype != torch.float32:
+        raise BtsHipError("bts_amd.%s: expected float32, got %s" % (name, t.dtype))
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _rows2d(t: torch.Tensor, name: str) -> Tuple[int, int]:
+    """A [npix, C] NHWC view: unit channel stride, arbitrary (>= C) pixel stride."""
+    _need(t, name)
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        raise BtsHipError("bts_amd.%s: expected a [npix, C] view with unit channel stride" % name)
+    return t.stride(0), t.shape[1]
+
+
+# ------------------------------------------------------------------------------ LPG
+def lpg_forward(plane_eq: torch.Tensor, upratio: int, abs_min: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """local_planar_guidance.forward (reference bts.py:149-173): [B,4,h,w] -> [B,h*k,w*k]."""
+    _need(plane_eq, "lpg_forward")
+    if plane_eq.dim() != 4 or plane_eq.shape[1] != 4:
+        raise BtsHipError("lpg_forward: plane_eq must be [B,4,h,w]")
+    plane_eq = plane_eq.contiguous()
+    B, _, h, w = plane_eq.shape
+    k = int(upratio)
+    out = torch.empty((B, h * k, w * k), dtype=torch.float32, device=plane_eq.device)
+    with torch.cuda.device(plane_eq.device):
+        rc = _lib.load().bts_lpg_fwd_f32(_ptr(plane_eq), B, h, w, k, _ptr(out), _ptr(abs_min), _stream(plane_eq))
+    _lib.check(rc, "bts_lpg_fwd_f32")
+    return out
+
+
+def lpg_fused_forward(plane4: torch.Tensor, B: int, h: int, w: int, upratio: int, max_depth: float,
+                      normalize: bool, depth_scaled: torch.Tensor, ds_out: Optional[torch.Tensor] = None,
+                      ds_factor: int = 1, ds_pix_stride: int = 1, abs_min: Optional[torch.Tensor] = None):
+    """LPG + glue of bts.forward (reference bts.py:250-256): plane4 [B*h*w,4] -> depth/max_depth."""
+    _need(plane4, "lpg_fused_forward")
+    _need(depth_scaled, "lpg_fused_forward")
+    k = int(upratio)
+    if plane4.numel() != B * h * w * 4 or not plane4.is_contiguous():
+        raise BtsHipError("lpg_fused_forward: plane4 must be contiguous [B*h*w,4]")
+    if depth_scaled.numel() != B * h * k * w * k or not depth_scaled.is_contiguous():
+        raise BtsHipError("lpg_fused_forward: depth_scaled must be contiguous [B,1,h*k,w*k]")
+    with torch.cuda.device(plane4.device):
+        rc = _lib.load().bts_lpg_fused_fwd_f32(_ptr(plane4), B, h, w, k, int(bool(normalize)), float(max_depth),
+                                               _ptr(depth_scaled), _ptr(ds_out), int(ds_factor), int(ds_pix_stride),
+                                               _ptr(abs_min), _stream(plane4))
+    _lib.check(rc, "bts_lpg_fused_fwd_f32")
+    return depth_scaled
+
+
+# ------------------------------------------------------------------------ reduction
+def reduc_chain(num_in: int, num_out: int) -> List[Tuple[int, int]]:
+    """(cin, cout_real) per layer, mirroring the while-loop of reduction_1x1.__init__ (bts.py:105-122).
+    The last entry's cout is filled by the caller's weights (3 or 1)."""
+    layers = []
+    while num_out >= 4:
+        if num_out < 8:
+            layers.append((num_in, -1))
+            break
+        layers.append((num_in, num_out))
+        num_in, num_out = num_out, num_out // 2
+    return layers
+
+
+def pack_reduc_weights(weights: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Pack a reduction chain's 1x1 weights ([cout,cin,1,1] each) into MFMA fragment order.
+
+    Per layer (K=cin, rows padded to 32*MT): float4 index ((mt*(K/8)+g)*64 + 32*h + i) holds
+    W[32*mt+i][4*(2g+h) + 0..3]  -- lane (i,h) of v_mfma_f32_32x32x2_f32's A operand for the four
+    k-steps of group g (see csrc/reduc.hip)."""
+    parts = []
+    for w in weights:
+        cout, cin = w.shape[0], w.shape[1]
+        assert cin % 8 == 0, "reduction chain widths are multiples of 8"
+        mt = (cout + 31) // 32
+        wp = torch.zeros((mt * 32, cin), dtype=torch.float32, device=w.device)
+        wp[:cout] = w.reshape(cout, cin).float()
+        # (mt, i, g, h, q) -> (mt, g, h, i, q)
+        parts.append(wp.view(mt, 32, cin // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1))
+    return torch.cat(parts).contiguous()
+
+
+def reduc_forward_nhwc(x2d: torch.Tensor, c_in: int, c_first_out: int, w_frag: torch.Tensor, max_depth: float,
+                       is_final: bool, normalize: bool, out: torch.Tensor):
+    """x2d: [npix, >=c_in] NHWC view; out: [npix,4] (non-final) or [npix] (final), contiguous."""
+    stride, cview = _rows2d(x2d, "reduc_forward_nhwc")
+    _need(out, "reduc_forward_nhwc")
+    _need(w_frag, "reduc_forward_nhwc")
+    if cview < c_in:
+        raise BtsHipError("reduc_forward_nhwc: view has %d channels, chain needs %d" % (cview, c_in))
+    npix = x2d.shape[0]
+    if out.numel() != npix * (1 if is_final else 4) or not out.is_contiguous():
+        raise BtsHipError("reduc_forward_nhwc: bad output size")
+    with torch.cuda.device(x2d.device):
+        rc = _lib.load().bts_reduc_fwd_f32(_ptr(x2d), stride, npix, int(c_in), int(c_first_out), _ptr(w_frag),
+                                           w_frag.numel(), float(max_depth), int(bool(is_final)),
+                                           int(bool(normalize)), _ptr(out), _stream(x2d))
+    _lib.check(rc, "bts_reduc_fwd_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------- layout
+def nchw_to_nhwc(src: torch.Tensor, dst2d: torch.Tensor, relu: bool = False):
+    """src [B,C,H,W] contiguous -> dst2d [B*H*W, C] view (channel slice of an NHWC buffer)."""
+    _need(src, "nchw_to_nhwc")
+    stride, cview = _rows2d(dst2d, "nchw_to_nhwc")
+    src = src.contiguous()
+    B, Cc, H, W = src.shape
+    if cview != Cc or dst2d.shape[0] != B * H * W:
+        raise BtsHipError("nchw_to_nhwc: destination view shape mismatch")
+    with torch.cuda.device(src.device):
+        rc = _lib.load().bts_nchw_to_nhwc_f32(_ptr(src), B, Cc, H * W, _ptr(dst2d), stride, int(bool(relu)), _stream(src))
+    _lib.check(rc, "bts_nchw_to_nhwc_f32")
+    return dst2d
+
+
+def nhwc_to_nchw(src2d: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    stride, Cc = _rows2d(src2d, "nhwc_to_nchw")
+    if src2d.shape[0] != B * H * W:
+        raise BtsHipError("nhwc_to_nchw: source view shape mismatch")
+    dst = torch.empty((B, Cc, H, W), dtype=torch.float32, device=src2d.device)
+    with torch.cuda.device(src2d.device):
+        rc = _lib.load().bts_nhwc_to_nchw_f32(_ptr(src2d), stride, B, Cc, H * W, _ptr(dst), _stream(src2d))
+    _lib.check(rc, "bts_nhwc_to_nchw_f32")
+    return dst
+
+
+# ------------------------------------------------------------------------------ conv
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def pack_conv_weight(w: torch.Tensor, perm: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int, int]:
+    """[cout,cin,k,k] -> packed [k*k][cout_pad][k_pad] (tap-major, K-contiguous), zero padded.
+    ``perm``: optional LongTensor; buffer channel j reads reference input channel perm[j]
+    (lets a concat buffer keep its own channel order).  Returns (packed, cout_pad, k_pad)."""
+    cout, cin, kh, kw = w.shape
+    wf = w.float()
+    if perm is not None:
+        wf = wf[:, perm.to(w.device)]
+    cout_pad, k_pad = round_up(cout, 32), round_up(cin, 32)
+    p = torch.zeros((kh * kw, cout_pad, k_pad), dtype=torch.float32, device=w.device)
+    p[:, :cout, :cin] = wf.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
+    return p.contiguous(), cout_pad, k_pad
+
+
+def pad_vec(v: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[torch.Tensor]:
+    if v is None:
+        return None
+    out = torch.full((n,), fill, dtype=torch.float32, device=v.device)
+    out[: v.numel()] = v.float().reshape(-1)
+    return out
+
+
+def bn_affine(weight, bias, mean, var, eps: float):
+    """Eval-mode BatchNorm as y = x*scale + shift (ATen batch_norm_cpu_transform_input form)."""
+    invstd = 1.0 / torch.sqrt(var.float() + eps)
+    scale = weight.float() * invstd
+    shift = bias.float() - mean.float() * scale
+    return scale, shift
+
+
+def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torch.Tensor, c_out: int,
+                 ksize: int, dil: int = 1, up: int = 1, c_in_ld: Optional[int] = None,
+                 pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_relu: bool = False,
+                 e1: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, act: int = ACT_NONE,
+                 e2: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                 y2d: Optional[torch.Tensor] = None, y_nchw: Optional[torch.Tensor] = None):
+    """One fused convolution (see bts_conv_desc in include/bts_hip.h).
+
+    x2d: [B*h_in*w_in, C>=c_in_ld] NHWC view.  Exactly one of y2d ([B*H*W, c_out] NHWC view) /
+    y_nchw ([B,c_out,H,W] contiguous) receives the result."""
+    xs, xc = _rows2d(x2d, "conv_forward")
+    _need(w_packed, "conv_forward")
+    taps, c_out_pad, k_pad = w_packed.shape
+    if taps != ksize * ksize or not w_packed.is_contiguous():
+        raise BtsHipError("conv_forward: packed weight/ksize mismatch")
+    if c_in_ld is None:
+        c_in_ld = xc
+    if c_in_ld % 4 or c_in_ld > xc or x2d.shape[0] != B * h_in * w_in:
+        raise BtsHipError("conv_forward: bad input view (c_in_ld %d, view %s)" % (c_in_ld, tuple(x2d.shape)))
+    H, W = h_in * up, w_in * up
+    d = ConvDesc()
+    d.x, d.x_pix_stride, d.c_in_ld, d.k_pad = x2d.data_ptr(), xs, c_in_ld, k_pad
+    d.B, d.h_in, d.w_in, d.up, d.ksize, d.dil = B, h_in, w_in, up, ksize, dil
+    d.w, d.c_out, d.c_out_pad = w_packed.data_ptr(), c_out, c_out_pad
+    keep = []
+    for name, pair, n in (("pre", pre, k_pad), ("e1", e1, c_out_pad), ("e2", e2, c_out_pad)):
+        if pair is not None:
+            s, b = pair
+            if s.numel() != n or b.numel() != n:
+                raise BtsHipError("conv_forward: %s vectors must have %d elements" % (name, n))
+            _need(s, "conv_forward")
+            _need(b, "conv_forward")
+            keep += [s, b]
+            setattr(d, name + "_scale", s.data_ptr())
+            setattr(d, name + "_shift", b.data_ptr())
+    d.pre_relu, d.act = int(bool(pre_relu)), int(act)
+    if (y2d is None) == (y_nchw is None):
+        raise BtsHipError("conv_forward: give exactly one of y2d / y_nchw")
+    if y2d is not None:
+        ys, yc = _rows2d(y2d, "conv_forward")
+        if yc != c_out or y2d.shape[0] != B * H * W:
+            raise BtsHipError("conv_forward: bad output view")
+        d.y, d.y_pix_stride, d.y_nchw = y2d.data_ptr(), ys, 0
+        out = y2d
+    else:
+        _need(y_nchw, "conv_forward")
+        if tuple(y_nchw.shape) != (B, c_out, H, W) or not y_nchw.is_contiguous():
+            raise BtsHipError("conv_forward: y_nchw must be contiguous [B,c_out,H,W]")
+        d.y, d.y_pix_stride, d.y_nchw = y_nchw.data_ptr(), 0, 1
+        out = y_nchw
+    with torch.cuda.device(x2d.device):
+        rc = _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d))
+    _lib.check(rc, "bts_conv_fwd_f32")
+    return out

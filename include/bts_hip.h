@@ -1,0 +1,133 @@
+/*
+ * bts_hip.h -- C ABI of libbts_hip.so: the MI355X (gfx950) native BTS decoder hot path.
+ *
+ * Drop-in boundary for the hot path of minghanz/bts (reference files cited per entry,
+ * paths relative to the reference checkout).  Conventions mirror the only native
+ * interface the reference has, LocalPlanarGuidanceKernel<Device>::operator()
+ * (tensorflow/custom_layer/local_planar_guidance.h:22-49): borrowed `const float*`
+ * inputs, caller-allocated outputs, dims as `int`, work enqueued on a caller stream.
+ *
+ *  - all pointers are DEVICE pointers to fp32 unless stated; the caller owns every buffer;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *  - nothing here allocates, frees or synchronises: calls are hipGraph-capturable;
+ *  - return value: 0 = ok, >0 = a hipError_t from the launch, <0 = BTS_ERR_* (bad
+ *    arguments); errors are raised by the wrapper, never thrown across the ABI
+ *    (cf. OP_REQUIRES / errors::InvalidArgument in local_planar_guidance.cc:36-44,123);
+ *  - the library holds no global mutable state and is re-entrant per (device, stream).
+ */
+#ifndef BTS_HIP_H_
+#define BTS_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BTS_HIP_ABI_VERSION 1
+
+#define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
+#define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
+
+typedef void* bts_stream_t;
+
+int         bts_hip_abi_version(void);
+const char* bts_hip_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Local planar guidance, forward.
+ * Replaces local_planar_guidance.forward (pytorch/bts.py:149-173); native statement:
+ * LocalPlanarGuidanceKernel<GPUDevice> (tensorflow/custom_layer/local_planar_guidance.cu:33-72).
+ *
+ *   plane_eq : [B,4,h,w] NCHW planar (n1,n2,n3,n4), as the PyTorch module receives it
+ *   depth    : [B,h*k,w*k]
+ *   abs_min  : optional 1-float device scalar <- min |n1*u+n2*v+n3| (bts.py:167), may be NULL
+ * Bit-exact with the reference on the same inputs: separate mul/add roundings (no FMA),
+ * the +-1e-3 clamp of bts.py:168-171 and an IEEE division.  upratio in {1,2,4,8}.
+ */
+int bts_lpg_fwd_f32(const float* plane_eq, int B, int h, int w, int upratio,
+                    float* depth, float* abs_min, bts_stream_t stream);
+
+/* Fused LPG + glue, as bts.forward uses it (pytorch/bts.py:250-256, 264-270, 278-283):
+ *   plane4   : [B*h*w,4] cell-interleaved (n1,n2,n3,n4) -- what bts_reduc_fwd_f32 emits
+ *   normalize: !=0 -> n[0:3] /= max(||n||_2, 1e-12)  (F.normalize, bts.py:251); 0 if already done
+ *   depth_scaled : [B,1,h*k,w*k] = lpg(plane)/max_depth                      (bts.py:255)
+ *   ds_out   : optional nearest-downsampled copy [::ds_factor, ::ds_factor] (bts.py:256,270),
+ *              element (b,y,x) written at ds_out[((b*Hd+y)*Wd+x)*ds_pix_stride]; NULL to skip
+ *   abs_min  : optional, as above
+ */
+int bts_lpg_fused_fwd_f32(const float* plane4, int B, int h, int w, int upratio, int normalize,
+                          float max_depth, float* depth_scaled,
+                          float* ds_out, int ds_factor, long ds_pix_stride,
+                          float* abs_min, bts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * reduction_1x1 forward: the whole 1x1-conv(+ELU) chain and its epilogue in one kernel.
+ * Replaces reduction_1x1.forward (pytorch/bts.py:97-136).
+ *
+ *   x        : NHWC activations, pixel p channel c at x[p*x_pix_stride + c], c in [0,c_in)
+ *   npix     : B*h*w
+ *   c_in, c_first_out : the module's (num_in_filters, num_out_filters); the chain halves the
+ *              width until it is < 8 exactly as bts.py:105-122 does.  Built chains:
+ *              (128,128) (128,64) (64,32) (32,16).
+ *   w_frag   : the chain's weights in MFMA fragment order (see bts_amd/ops.py:pack_reduc_weights)
+ *   is_final : 0 -> out[p*4 + {0..3}] = (sin t cos f, sin t sin f, cos t, sigmoid(c2)*max_depth)
+ *                   with t = sigmoid(c0)*pi/3, f = sigmoid(c1)*2pi (bts.py:127-134); if
+ *                   `normalize` the normal is L2-normalised here (bts.py:251) so LPG need not;
+ *              1 -> out[p] = sigmoid(c0) (bts.py:108-110)
+ */
+int bts_reduc_fwd_f32(const float* x, long x_pix_stride, long npix, int c_in, int c_first_out,
+                      const float* w_frag, long w_frag_floats, float max_depth, int is_final,
+                      int normalize, float* out, bts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * NHWC implicit-GEMM convolution on fp32-input MFMA (v_mfma_f32_32x32x2_f32), with fused
+ * per-channel affine/activation prologue and epilogue.  Covers atrous_conv's two convolutions
+ * (pytorch/bts.py:65-80: [first_bn]->ReLU->conv1x1->BN->ReLU->conv3x3 dilated) and the other
+ * decoder convolutions (upconv bts.py:83-94, conv5..conv1, daspp_conv bts.py:183-221).
+ *
+ *   y[p, n] = E( sum_{tap,c} P(x[q(p,tap), c]) * w[tap][n][c] )
+ *   P(v) = pre_relu( v*pre_scale[c] + pre_shift[c] )         (zero padding applied AFTER P)
+ *   E(a) = post2( act( a*e1_scale[n] + e1_shift[n] ) ),  post2(v) = v*e2_scale[n] + e2_shift[n]
+ *   q(p,tap): input pixel of output pixel p for the tap, with `dil` dilation, padding
+ *   dil*(ksize/2) and an optional nearest `up`x upsample of the input folded into the index.
+ */
+typedef struct bts_conv_desc {
+    const float* x;        /* input, NHWC: pixel q channel c at x[q*x_pix_stride + c]              */
+    long  x_pix_stride;    /* floats between pixels (>= c_in_ld, multiple of 4)                   */
+    int   c_in_ld;         /* loadable input channels (multiple of 4; pad channels must be 0)     */
+    int   k_pad;           /* per-tap K of the packed weights (multiple of 32, >= c_in_ld)        */
+    int   B, h_in, w_in;   /* input spatial size before the optional upsample                     */
+    int   up;              /* 1 or 2: nearest upsample folded into the gather (bts.py:91)         */
+    int   ksize;           /* 1 or 3                                                               */
+    int   dil;             /* dilation (= padding) for ksize 3                                     */
+    const float* w;        /* packed weights [ksize*ksize][c_out_pad][k_pad], c_out_pad % 32 == 0  */
+    int   c_out;           /* real output channels                                                 */
+    int   c_out_pad;
+    const float* pre_scale;  /* [k_pad] or NULL (identity)                                         */
+    const float* pre_shift;  /* [k_pad] or NULL                                                    */
+    int   pre_relu;
+    const float* e1_scale;   /* [c_out_pad] or NULL                                                */
+    const float* e1_shift;
+    int   act;               /* 0 none, 1 ReLU, 2 ELU, 3 sigmoid                                   */
+    const float* e2_scale;   /* [c_out_pad] or NULL                                                */
+    const float* e2_shift;
+    float* y;                /* output                                                             */
+    long  y_pix_stride;      /* NHWC: floats between pixels; ignored for NCHW                      */
+    int   y_nchw;            /* 0: y[p*y_pix_stride + n]; 1: y[(b*c_out + n)*H*W + yx] (boundary)  */
+} bts_conv_desc;
+
+int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout movers between the NCHW boundary (pytorch/bts.py:347-349 tensors) and the NHWC
+ * interior.  dst/src NHWC element (p,c) lives at base[p*pix_stride + c].
+ *   relu != 0 applies max(v,0) on the way (bts.py:225: dense_features = ReLU(features[5])).
+ */
+int bts_nchw_to_nhwc_f32(const float* src, int B, int C, long HW, float* dst, long dst_pix_stride,
+                         int relu, bts_stream_t stream);
+int bts_nhwc_to_nchw_f32(const float* src, long src_pix_stride, int B, int C, long HW, float* dst,
+                         bts_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTS_HIP_H_ */

@@ -1,0 +1,277 @@
+"""GPU parity: each C-ABI entry point (include/bts_hip.h) against the CPU oracle and the
+reference-generated goldens, on seeded inputs.  fp32 throughout.
+
+Tolerances: LPG standalone is asserted BIT-EXACT (same roundings as the reference); kernels
+with contractions/transcendentals are asserted at rtol 1e-4 (north_star budget is 1e-3; the
+fp32 noise floor of the reference itself is ~2e-6) with a small atol for values crossing 0.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bts_amd import synth
+from oracle import bts_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {"K": ("densenet161_bts", 80.0), "N": ("resnext101_bts", 10.0)}
+MOD_SHAPES = [(2, 11, 19), (1, 13, 17)]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bts_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def states():
+    return {c: O.state_from_numpy(synth.decoder_state(synth.ENCODER_CHANNELS[v[0]], 512, 0))
+            for c, v in CONFIGS.items()}
+
+
+def dev(a):
+    if isinstance(a, np.ndarray):
+        a = torch.from_numpy(np.ascontiguousarray(a))
+    return a.cuda()
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, what=""):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    bad = ~(err <= tol)
+    assert not bad.any(), "%s: %d/%d mismatches, max abs err %g, max rel %g" % (
+        what, bad.sum(), bad.size, np.nanmax(err), np.nanmax(err / (np.abs(b) + 1e-12)))
+
+
+# ------------------------------------------------------------------------------ LPG
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_lpg_golden_bitexact(ops, golden_dir, k):
+    g = np.load(os.path.join(golden_dir, "lpg_tables.npz"))
+    for name in ("hand", "orient", "rand"):
+        x = g["%s_%d_in" % (name, k)]      # widths 18/14/6 at k=2 also exercise the non-vectorised path
+        am = torch.zeros(1, device="cuda")
+        y = ops.lpg_forward(dev(x), k, abs_min=am).cpu().numpy()
+        ref, ref_am = O.lpg_forward(torch.from_numpy(x), k)
+        assert np.array_equal(y, ref.numpy(), equal_nan=True)
+        assert am.item() == ref_am.item()
+        assert np.array_equal(y, g["%s_%d_out" % (name, k)], equal_nan=True)
+        assert np.float32(am.item()) == g["%s_%d_absmin" % (name, k)]
+
+
+@pytest.mark.parametrize("k,shape", [(8, (2, 44, 152)), (4, (2, 88, 304)), (2, (1, 176, 608)), (1, (1, 8, 12)),
+                                     (8, (1, 3, 5)), (2, (3, 7, 10))])
+def test_lpg_random_bitexact(ops, k, shape):
+    B, h, w = shape
+    rng = np.random.Generator(np.random.PCG64(7 + k))
+    x = rng.standard_normal(size=(B, 4, h, w)).astype(np.float32)
+    x[:, 2] *= 0.05                       # many denominators near/through 0 -> exercises both clamps
+    am = torch.zeros(1, device="cuda")
+    y = ops.lpg_forward(dev(x), k, abs_min=am).cpu().numpy()
+    ref, ref_am = O.lpg_forward(torch.from_numpy(x), k)
+    assert np.array_equal(y, ref.numpy(), equal_nan=True)
+    assert am.item() == ref_am.item()
+    den = O.lpg_denominator(torch.from_numpy(x), k).numpy()
+    if den.size > 100000:
+        assert ((np.abs(den) < 1e-3) & (den != 0)).sum() > 0, "test must hit the clamp branch"
+
+
+def test_lpg_rejects_bad_upratio(ops):
+    x = torch.zeros(1, 4, 4, 4, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.lpg_forward(x, 3)
+    with pytest.raises(RuntimeError):
+        ops.lpg_forward(x.cpu(), 2)       # no CPU fallback
+
+
+@pytest.mark.parametrize("k,ds", [(8, 4), (4, 2), (2, 1)])
+def test_lpg_fused(ops, k, ds):
+    """normalize + LPG + /max_depth + nearest downsample (bts.py:250-256) in one launch."""
+    B, h, w = 2, 6, 10
+    rng = np.random.Generator(np.random.PCG64(50 + k))
+    red = rng.standard_normal(size=(B, 4, h, w)).astype(np.float32)
+    red[:, 3] = np.abs(red[:, 3]) * 20
+    max_depth = 80.0
+    t = torch.from_numpy(red)
+    pe = torch.cat([F.normalize(t[:, :3], 2, 1), t[:, 3:4]], 1)
+    ref, ref_am = O.lpg_forward(pe, k)
+    ref = ref.unsqueeze(1) / max_depth
+    plane4 = dev(red).permute(0, 2, 3, 1).contiguous().view(-1, 4)
+    out = torch.empty(B, 1, h * k, w * k, device="cuda")
+    am = torch.zeros(1, device="cuda")
+    H, W = h * k, w * k
+    stride = 5
+    dsbuf = torch.zeros(B * (H // ds) * (W // ds), stride, device="cuda")
+    ops.lpg_fused_forward(plane4, B, h, w, k, max_depth, True, out,
+                          ds_out=dsbuf[:, 3] if ds > 1 else None, ds_factor=ds, ds_pix_stride=stride, abs_min=am)
+    den = O.lpg_denominator(pe, k).unsqueeze(1).numpy()
+    mask = np.abs(den) > 2e-3
+    o = out.cpu().numpy()
+    r = ref.numpy()
+    close(o[mask], r[mask], rtol=2e-5, atol=1e-6, what="fused lpg k=%d" % k)
+    assert abs(am.item() - ref_am.item()) <= 1e-6
+    if ds > 1:
+        ref_ds = F.interpolate(torch.from_numpy(o), scale_factor=1.0 / ds, mode="nearest").numpy()
+        got = dsbuf[:, 3].cpu().numpy().reshape(B, 1, H // ds, W // ds)
+        assert np.array_equal(got, ref_ds, equal_nan=True)
+        assert torch.count_nonzero(dsbuf[:, :3]).item() == 0     # neighbours of the strided slot untouched
+
+
+# ------------------------------------------------------------------------ reduction
+REDUCS = {"reduc8x8": (128, 128, False), "reduc4x4": (128, 64, False), "reduc2x2": (64, 32, False),
+          "reduc1x1": (32, 16, True)}
+
+
+def _run_reduc(ops, x_nchw, ws, cin, cfirst, md, fin, stride_pad=0):
+    B, Cc, h, w = x_nchw.shape
+    buf = torch.zeros(B * h * w, Cc + stride_pad, device="cuda")
+    ops.nchw_to_nhwc(dev(x_nchw), buf[:, :Cc])
+    frag = ops.pack_reduc_weights([dev(wt) for wt in ws])
+    out = torch.empty(B * h * w * (1 if fin else 4), device="cuda")
+    ops.reduc_forward_nhwc(buf[:, :Cc], cin, cfirst, frag, md, fin, False, out)
+    if fin:
+        return out.view(B, 1, h, w)
+    return out.view(B, h, w, 4).permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("cname", ["K", "N"])
+@pytest.mark.parametrize("name", list(REDUCS))
+def test_reduction_vs_oracle_and_golden(ops, golden_dir, states, cname, name):
+    g = np.load(os.path.join(golden_dir, "modules_small.npz"))
+    cin, cfirst, fin = REDUCS[name]
+    ws = O._reduc_weights(states[cname], name)
+    for md in (80.0, 10.0):
+        for si, (B, h, w) in enumerate(MOD_SHAPES):
+            rng = np.random.Generator(np.random.PCG64(2000 + si))
+            x = rng.standard_normal(size=(B, cin, h, w), dtype=np.float32)
+            y = _run_reduc(ops, torch.from_numpy(x), ws, cin, cfirst, md, fin, stride_pad=4 * si)
+            ref = O.reduction_forward(torch.from_numpy(x), ws, md, fin)
+            close(y, ref, rtol=1e-4, atol=1e-5, what="%s %s vs oracle" % (cname, name))
+            close(y, g["%s_%s_md%d_s%d" % (cname, name, int(md), si)], rtol=1e-4, atol=1e-5,
+                  what="%s %s vs golden" % (cname, name))
+
+
+def test_reduction_ragged_and_large(ops, states):
+    """npix not a multiple of 32 (ragged last tile) and a multi-tile-per-wave size."""
+    for name, npix_shape in (("reduc2x2", (1, 5, 7)), ("reduc1x1", (3, 64, 100)), ("reduc8x8", (2, 44, 152))):
+        cin, cfirst, fin = REDUCS[name]
+        ws = O._reduc_weights(states["K"], name)
+        rng = np.random.Generator(np.random.PCG64(11))
+        x = rng.standard_normal(size=(npix_shape[0], cin) + npix_shape[1:], dtype=np.float32)
+        y = _run_reduc(ops, torch.from_numpy(x), ws, cin, cfirst, 80.0, fin)
+        ref = O.reduction_forward(torch.from_numpy(x), ws, 80.0, fin)
+        close(y, ref, rtol=1e-4, atol=1e-5, what=name)
+
+
+# ------------------------------------------------------------------------------ conv
+def _bn(p, prefix, eps, ops):
+    return ops.bn_affine(p[prefix + ".weight"], p[prefix + ".bias"], p[prefix + ".running_mean"],
+                         p[prefix + ".running_var"], eps)
+
+
+def _run_atrous(ops, p, name, x_nchw, dil, first_bn):
+    """atrous_conv (bts.py:65-80) as two fused conv launches."""
+    B, Cc, h, w = x_nchw.shape
+    a = name + ".atrous_conv"
+    xin = torch.zeros(B * h * w, Cc, device="cuda")
+    ops.nchw_to_nhwc(dev(x_nchw), xin)
+    w1, co1, k1 = ops.pack_conv_weight(dev(p[a + ".aconv_sequence.1.weight"]))
+    w2, co2, k2 = ops.pack_conv_weight(dev(p[a + ".aconv_sequence.4.weight"]))
+    pre = None
+    if first_bn:
+        s, b = _bn(p, a + ".first_bn", 1.1e-5, ops)
+        pre = (dev(ops.pad_vec(s, k1, 1.0)), dev(ops.pad_vec(b, k1, 0.0)))
+    s2, b2 = _bn(p, a + ".aconv_sequence.2", 1e-5, ops)
+    mid = torch.empty(B * h * w, 256, device="cuda")
+    ops.conv_forward(xin, B, h, w, w1, 256, 1, pre=pre, pre_relu=True,
+                     e1=(dev(ops.pad_vec(s2, co1, 1.0)), dev(ops.pad_vec(b2, co1, 0.0))), act=ops.ACT_RELU, y2d=mid)
+    out = torch.full((B * h * w, 128 + 8), -7.0, device="cuda")    # write into a channel slice
+    ops.conv_forward(mid, B, h, w, w2, 128, 3, dil=dil, y2d=out[:, 4:132])
+    assert (out[:, :4] == -7.0).all() and (out[:, 132:] == -7.0).all()
+    return ops.nhwc_to_nchw(out[:, 4:132], B, h, w)
+
+
+@pytest.mark.parametrize("cname", ["K", "N"])
+@pytest.mark.parametrize("name,dil,fbn,extra", [("daspp_3", 3, False, 0), ("daspp_6", 6, True, 128),
+                                                ("daspp_12", 12, True, 256), ("daspp_18", 18, True, 384),
+                                                ("daspp_24", 24, True, 512)])
+def test_atrous_vs_oracle_and_golden(ops, golden_dir, states, cname, name, dil, fbn, extra):
+    g = np.load(os.path.join(golden_dir, "modules_small.npz"))
+    p = states[cname]
+    feat = synth.ENCODER_CHANNELS[CONFIGS[cname][0]]
+    cin = 256 if not fbn else 256 + feat[2] + extra
+    for si, (B, h, w) in enumerate(MOD_SHAPES):
+        rng = np.random.Generator(np.random.PCG64(3000 + si))
+        x = rng.standard_normal(size=(B, cin, h, w), dtype=np.float32)
+        y = _run_atrous(ops, p, name, torch.from_numpy(x), dil, fbn)
+        ref = O.atrous_forward(torch.from_numpy(x), p, name, dil, fbn)
+        close(y, ref, rtol=1e-4, atol=2e-5, what="%s %s vs oracle" % (cname, name))
+        close(y, g["%s_%s_s%d" % (cname, name, si)], rtol=1e-4, atol=2e-5, what="%s %s vs golden" % (cname, name))
+
+
+@pytest.mark.parametrize("cin,cout,up,act,nchw", [(36, 32, 1, 2, True), (64, 32, 2, 2, False), (161, 64, 1, 2, False),
+                                                  (225, 128, 1, 2, False), (96, 256, 2, 2, False),
+                                                  (40, 1, 1, 3, True), (32, 96, 1, 0, True)])
+def test_conv3x3_generic(ops, cin, cout, up, act, nchw):
+    """upconv (nearest x2 + conv3x3 + ELU + BN, bts.py:83-94,226-227) and plain conv3x3+ELU blocks,
+    odd channel counts (36/161/225), NHWC-slice and NCHW outputs."""
+    B, h, w = 2, 9, 14
+    rng = np.random.Generator(np.random.PCG64(cin * 7 + cout))
+    x = rng.standard_normal(size=(B, cin, h, w), dtype=np.float32)
+    wt = (rng.standard_normal(size=(cout, cin, 3, 3)) * 0.05).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, size=cout).astype(np.float32)
+    sh = rng.standard_normal(size=cout).astype(np.float32) * 0.1
+    xt = torch.from_numpy(x)
+    ref = F.conv2d(F.interpolate(xt, scale_factor=up, mode="nearest") if up > 1 else xt, torch.from_numpy(wt), padding=1)
+    ref = {0: lambda v: v, 2: F.elu, 3: torch.sigmoid}[act](ref)
+    ref = ref * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1)
+    cin_ld = ops.round_up(cin, 4)
+    xin = torch.zeros(B * h * w, cin_ld, device="cuda")
+    ops.nchw_to_nhwc(dev(x), xin[:, :cin])
+    wp, cop, kp = ops.pack_conv_weight(dev(wt))
+    e2 = (dev(ops.pad_vec(torch.from_numpy(sc), cop, 1.0)), dev(ops.pad_vec(torch.from_numpy(sh), cop, 0.0)))
+    H, W = h * up, w * up
+    if nchw:
+        y = torch.empty(B, cout, H, W, device="cuda")
+        ops.conv_forward(xin, B, h, w, wp, cout, 3, dil=1, up=up, c_in_ld=cin_ld, act=act, e2=e2, y_nchw=y)
+    else:
+        yb = torch.zeros(B * H * W, cout, device="cuda")
+        ops.conv_forward(xin, B, h, w, wp, cout, 3, dil=1, up=up, c_in_ld=cin_ld, act=act, e2=e2, y2d=yb)
+        y = ops.nhwc_to_nchw(yb, B, H, W)
+    close(y, ref, rtol=1e-4, atol=2e-5, what="conv3x3 %d->%d up%d" % (cin, cout, up))
+
+
+def test_conv_k_permutation(ops):
+    """pack_conv_weight(perm=...) lets the NHWC buffer keep its own channel order."""
+    B, h, w, cin, cout = 1, 6, 8, 48, 32
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = rng.standard_normal(size=(B, cin, h, w), dtype=np.float32)
+    wt = (rng.standard_normal(size=(cout, cin, 3, 3)) * 0.1).astype(np.float32)
+    perm = torch.from_numpy(rng.permutation(cin))
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(wt), padding=1)
+    xin = torch.zeros(B * h * w, cin, device="cuda")
+    ops.nchw_to_nhwc(dev(x[:, perm.numpy()]), xin)       # buffer channel j = reference channel perm[j]
+    wp, cop, kp = ops.pack_conv_weight(dev(wt), perm=perm)
+    yb = torch.zeros(B * h * w, cout, device="cuda")
+    ops.conv_forward(xin, B, h, w, wp, cout, 3, y2d=yb)
+    close(ops.nhwc_to_nchw(yb, B, h, w), ref, rtol=1e-4, atol=2e-5)
+
+
+def test_layout_roundtrip(ops):
+    rng = np.random.Generator(np.random.PCG64(3))
+    x = rng.standard_normal(size=(3, 37, 5, 9), dtype=np.float32)
+    buf = torch.zeros(3 * 45, 44, device="cuda")
+    ops.nchw_to_nhwc(dev(x), buf[:, 4:41])
+    ref = torch.from_numpy(x).permute(0, 2, 3, 1).reshape(-1, 37)
+    assert torch.equal(buf[:, 4:41].cpu(), ref)
+    assert torch.count_nonzero(buf[:, :4]).item() == 0 and torch.count_nonzero(buf[:, 41:]).item() == 0
+    assert torch.equal(ops.nhwc_to_nchw(buf[:, 4:41], 3, 5, 9).cpu(), torch.from_numpy(x))
+    ops.nchw_to_nhwc(dev(x), buf[:, 4:41], relu=True)
+    assert torch.equal(buf[:, 4:41].cpu(), ref.clamp_min(0))
