@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libbts_hip.so")
 SYMBOLS = (
     "bts_hip_abi_version", "bts_hip_error_string", "bts_lpg_fwd_f32", "bts_lpg_fused_fwd_f32",
     "bts_reduc_fwd_f32", "bts_conv_fwd_f32", "bts_nchw_to_nhwc_f32", "bts_nhwc_to_nchw_f32",
+    "bts_pack_planes_f32", "bts_get_depth_f32",
 )
 
 ABI_VERSION = 1
@@ -70,6 +71,10 @@ def load():
     lib.bts_nchw_to_nhwc_f32.argtypes = [vp, i, i, l, vp, l, i, vp]
     lib.bts_nhwc_to_nchw_f32.restype = i
     lib.bts_nhwc_to_nchw_f32.argtypes = [vp, l, i, i, l, vp, vp]
+    lib.bts_pack_planes_f32.restype = i
+    lib.bts_pack_planes_f32.argtypes = [vp, vp, vp, vp, i, l, vp, l, vp]
+    lib.bts_get_depth_f32.restype = i
+    lib.bts_get_depth_f32.argtypes = [vp, vp, i, i, i, i, f, vp, vp, vp]
     if lib.bts_hip_abi_version() != ABI_VERSION:
         raise BtsHipError("bts_amd: ABI version mismatch (%d != %d)" % (lib.bts_hip_abi_version(), ABI_VERSION))
     _lib = lib

@@ -1,0 +1,512 @@
+"""Drop-in model plugin: the names, constructor signatures, attribute tree and state_dict keys of
+the reference ``pytorch/bts.py`` with the decoder hot path running on hand-written HIP kernels.
+
+The reference's callers load the model file as a plugin --
+``for k, v in vars(__import__(args.model_name)).items(): vars()[k] = v`` (bts_test.py:70-76,
+bts_eval.py:72-78, bts_main.py:63-76) -- then ``BtsModel(params=args)``, ``load_state_dict``,
+``.eval()``, ``.cuda()``, ``model(image, focal)`` -> 6 NCHW fp32 tensors (bts_test.py:90-138).
+This module exports the same symbols (``BtsModel, encoder, bts, atrous_conv, upconv,
+reduction_1x1, local_planar_guidance, silog_loss, depth_l1_loss, weights_init_xavier,
+bn_init_as_tf``); parameters live in ordinary nn.Conv2d / nn.BatchNorm2d modules so keys and
+shapes are identical to the reference (110 decoder entries), and are re-packed lazily into the
+kernels' layouts after ``load_state_dict``.
+
+Inside ``bts.forward`` everything is NHWC: every convolution of the decoder is one launch of the
+fp32-MFMA implicit-GEMM kernel with its BN/ReLU/ELU fused, concatenations are channel slices of
+preallocated buffers (no torch.cat), each reduction_1x1 stack is one kernel, each LPG one kernel.
+There is no PyTorch/CPU fallback: CPU tensors or a missing libbts_hip.so raise.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as torch_nn_func
+
+from . import ops
+from ._lib import BtsHipError
+from .encoders import build_base_model
+
+
+# ----------------------------------------------------------------- helpers kept from the reference API
+def bn_init_as_tf(m):
+    """bts.py:26-31."""
+    if isinstance(m, nn.BatchNorm2d):
+        m.track_running_stats = True
+        m.eval()
+        m.affine = True
+        m.requires_grad = True
+
+
+def weights_init_xavier(m):
+    """bts.py:34-38."""
+    if isinstance(m, nn.Conv2d):
+        torch.nn.init.xavier_uniform_(m.weight)
+        if m.bias is not None:
+            torch.nn.init.zeros_(m.bias)
+
+
+class silog_loss(nn.Module):
+    """bts.py:41-48 (plain torch; used by training callers, not on the inference hot path)."""
+
+    def __init__(self, variance_focus):
+        super(silog_loss, self).__init__()
+        self.variance_focus = variance_focus
+
+    def forward(self, depth_est, depth_gt, mask):
+        d = torch.log(depth_est[mask]) - torch.log(depth_gt[mask])
+        return torch.sqrt((d ** 2).mean() - self.variance_focus * (d.mean() ** 2)) * 10.0
+
+
+class depth_l1_loss(nn.Module):
+    """bts.py:50-63."""
+
+    def __init__(self, inbalance_to_closer):
+        super(depth_l1_loss, self).__init__()
+        self.inbalance_to_closer = inbalance_to_closer
+
+    def forward(self, depth_est, depth_gt, mask):
+        if self.inbalance_to_closer == 1:
+            d = torch.abs(depth_est[mask] - depth_gt[mask]).mean()
+        else:
+            err = depth_est[mask] - depth_gt[mask]
+            err_pos = self.inbalance_to_closer * err[err > 0]
+            err_neg = -err[err < 0]
+            total_num = err.numel()
+            d = (err_pos.sum() + err_neg.sum()) / total_num
+        return d
+
+
+def _bn_vecs(bn: nn.BatchNorm2d, n_pad: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eval-mode BN as padded (scale, shift) vectors."""
+    s, b = ops.bn_affine(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+    return ops.pad_vec(s, n_pad, 1.0), ops.pad_vec(b, n_pad, 0.0)
+
+
+def _param_key(module: nn.Module):
+    """Cheap fingerprint of a module's tensors: re-pack when load_state_dict/.cuda()/an optimizer touches them."""
+    return tuple((t.data_ptr(), t._version, str(t.device)) for t in list(module.parameters()) + list(module.buffers()))
+
+
+def _require_eval(m: nn.Module, what: str):
+    if m.training:
+        raise NotImplementedError(
+            "bts_amd.%s: only the eval-mode (inference) forward is built on HIP; call .eval() first. "
+            "Training (batch-stat BN + backward) is the next row of SURVEY.md section 8(f)." % what)
+
+
+def _nhwc_in(x: torch.Tensor, c_pad_to: int = 4) -> Tuple[torch.Tensor, int, int, int, int]:
+    """NCHW module-boundary tensor -> [npix, C_ld] NHWC buffer (zero pad channels)."""
+    ops._need(x, "forward")
+    B, C, H, W = x.shape
+    buf = torch.zeros((B * H * W, ops.round_up(C, c_pad_to)), dtype=torch.float32, device=x.device)
+    ops.nchw_to_nhwc(x, buf[:, :C])
+    return buf, B, C, H, W
+
+
+# ----------------------------------------------------------------------------------------- modules
+class atrous_conv(nn.Sequential):
+    """bts.py:65-80.  Same sub-module tree (atrous_conv.first_bn / aconv_sequence.{1,2,4})."""
+
+    def __init__(self, in_channels, out_channels, dilation, apply_bn_first=True):
+        super(atrous_conv, self).__init__()
+        self.atrous_conv = torch.nn.Sequential()
+        if apply_bn_first:
+            self.atrous_conv.add_module('first_bn', nn.BatchNorm2d(in_channels, momentum=0.01, affine=True,
+                                                                   track_running_stats=True, eps=1.1e-5))
+        self.atrous_conv.add_module('aconv_sequence', nn.Sequential(
+            nn.ReLU(),
+            nn.Conv2d(in_channels=in_channels, out_channels=out_channels * 2, bias=False, kernel_size=1, stride=1, padding=0),
+            nn.BatchNorm2d(out_channels * 2, momentum=0.01, affine=True, track_running_stats=True),
+            nn.ReLU(),
+            nn.Conv2d(in_channels=out_channels * 2, out_channels=out_channels, bias=False, kernel_size=3, stride=1,
+                      padding=(dilation, dilation), dilation=dilation)))
+        self.dilation = dilation
+        self.apply_bn_first = apply_bn_first
+        self._pack = None
+        self._pack_key = None
+
+    def packed(self):
+        key = _param_key(self)
+        if self._pack is None or self._pack_key != key:
+            seq = self.atrous_conv.aconv_sequence
+            w1, co1, k1 = ops.pack_conv_weight(seq[1].weight.detach())
+            w2, co2, k2 = ops.pack_conv_weight(seq[4].weight.detach())
+            pre = _bn_vecs(self.atrous_conv.first_bn, k1) if self.apply_bn_first else None
+            e1 = _bn_vecs(seq[2], co1)
+            self._pack = dict(w1=w1, w2=w2, pre=pre, e1=e1, c_mid=seq[1].out_channels, c_out=seq[4].out_channels,
+                              c_in=seq[1].in_channels)
+            self._pack_key = key
+        return self._pack
+
+    def run_nhwc(self, x2d, B, h, w, mid2d, y2d):
+        """Two launches: [BN]+ReLU -> 1x1 -> BN -> ReLU (mid), then dilated 3x3 into the y2d slice."""
+        p = self.packed()
+        ops.conv_forward(x2d, B, h, w, p["w1"], p["c_mid"], 1, c_in_ld=p["c_in"], pre=p["pre"], pre_relu=True,
+                         e1=p["e1"], act=ops.ACT_RELU, y2d=mid2d)
+        ops.conv_forward(mid2d, B, h, w, p["w2"], p["c_out"], 3, dil=self.dilation, y2d=y2d)
+
+    def forward(self, x):
+        _require_eval(self, "atrous_conv")
+        xin, B, C, h, w = _nhwc_in(x)
+        p = self.packed()
+        if C % 4:
+            raise BtsHipError("atrous_conv: in_channels must be a multiple of 4")
+        mid = torch.empty((B * h * w, p["c_mid"]), dtype=torch.float32, device=x.device)
+        out = torch.empty((B * h * w, p["c_out"]), dtype=torch.float32, device=x.device)
+        self.run_nhwc(xin, B, h, w, mid, out)
+        return ops.nhwc_to_nchw(out, B, h, w)
+
+
+class upconv(nn.Module):
+    """bts.py:83-94: nearest x2 (folded into the conv's gather) -> conv3x3 -> ELU."""
+
+    def __init__(self, in_channels, out_channels, ratio=2):
+        super(upconv, self).__init__()
+        self.elu = nn.ELU()
+        self.conv = nn.Conv2d(in_channels=in_channels, out_channels=out_channels, bias=False, kernel_size=3, stride=1, padding=1)
+        self.ratio = ratio
+        self._pack = None
+        self._pack_key = None
+
+    def packed(self):
+        key = _param_key(self)
+        if self._pack is None or self._pack_key != key:
+            self._pack = ops.pack_conv_weight(self.conv.weight.detach())
+            self._pack_key = key
+        return self._pack
+
+    def forward(self, x):
+        if self.ratio not in (1, 2):
+            raise BtsHipError("upconv: ratio %r not built (1 or 2)" % (self.ratio,))
+        xin, B, C, h, w = _nhwc_in(x)
+        wp, cop, kp = self.packed()
+        cout = self.conv.out_channels
+        y = torch.empty((B, cout, h * self.ratio, w * self.ratio), dtype=torch.float32, device=x.device)
+        ops.conv_forward(xin, B, h, w, wp, cout, 3, dil=1, up=self.ratio, act=ops.ACT_ELU, y_nchw=y)
+        return y
+
+
+class reduction_1x1(nn.Sequential):
+    """bts.py:97-136.  Same ``reduc`` sub-module names (inter_<in>_<out>, plane_params / final)."""
+
+    def __init__(self, num_in_filters, num_out_filters, max_depth, is_final=False):
+        super(reduction_1x1, self).__init__()
+        self.max_depth = max_depth
+        self.is_final = is_final
+        self.sigmoid = nn.Sigmoid()
+        self.reduc = torch.nn.Sequential()
+        self.c_in, self.c_first_out = num_in_filters, num_out_filters
+
+        while num_out_filters >= 4:
+            if num_out_filters < 8:
+                if self.is_final:
+                    self.reduc.add_module('final', torch.nn.Sequential(
+                        nn.Conv2d(num_in_filters, out_channels=1, bias=False, kernel_size=1, stride=1, padding=0),
+                        nn.Sigmoid()))
+                else:
+                    self.reduc.add_module('plane_params', torch.nn.Conv2d(num_in_filters, out_channels=3, bias=False,
+                                                                          kernel_size=1, stride=1, padding=0))
+                break
+            else:
+                self.reduc.add_module('inter_{}_{}'.format(num_in_filters, num_out_filters),
+                                      torch.nn.Sequential(nn.Conv2d(in_channels=num_in_filters, out_channels=num_out_filters,
+                                                                    bias=False, kernel_size=1, stride=1, padding=0),
+                                                          nn.ELU()))
+            num_in_filters = num_out_filters
+            num_out_filters = num_out_filters // 2
+        self._pack = None
+        self._pack_key = None
+
+    def packed(self) -> torch.Tensor:
+        key = _param_key(self)
+        if self._pack is None or self._pack_key != key:
+            ws = [m.weight.detach() for m in self.reduc.modules() if isinstance(m, nn.Conv2d)]
+            self._pack = ops.pack_reduc_weights(ws)
+            self._pack_key = key
+        return self._pack
+
+    def run_nhwc(self, x2d, out, normalize):
+        ops.reduc_forward_nhwc(x2d, self.c_in, self.c_first_out, self.packed(), self.max_depth, self.is_final,
+                               normalize, out)
+
+    def forward(self, net):
+        xin, B, C, h, w = _nhwc_in(net)
+        if self.is_final:
+            out = torch.empty((B, 1, h, w), dtype=torch.float32, device=net.device)
+            self.run_nhwc(xin[:, :C], out, False)
+            return out
+        out = torch.empty((B * h * w, 4), dtype=torch.float32, device=net.device)
+        self.run_nhwc(xin[:, :C], out, False)
+        return ops.nhwc_to_nchw(out, B, h, w)
+
+
+class local_planar_guidance(nn.Module):
+    """bts.py:138-173.  ``abs_min`` is kept as a device scalar (bts_main.py:484-486 reads it)."""
+
+    def __init__(self, upratio):
+        super(local_planar_guidance, self).__init__()
+        self.upratio = float(upratio)
+        self.abs_min = None
+
+    def forward(self, plane_eq, focal):
+        am = torch.empty((), dtype=torch.float32, device=plane_eq.device)
+        depth = ops.lpg_forward(plane_eq, int(self.upratio), abs_min=am)
+        self.abs_min = am
+        return depth
+
+
+# ----------------------------------------------------------------------------------------- decoder
+class bts(nn.Module):
+    """bts.py:175-293.  Same attribute names / state_dict; forward runs NHWC on HIP end to end."""
+
+    def __init__(self, params, feat_out_channels, num_features=512):
+        super(bts, self).__init__()
+        self.params = params
+        self.feat_out_channels = list(feat_out_channels)
+        self.num_features = num_features
+
+        self.upconv5 = upconv(feat_out_channels[4], num_features)
+        self.bn5 = nn.BatchNorm2d(num_features, momentum=0.01, affine=True, eps=1.1e-5)
+
+        self.conv5 = torch.nn.Sequential(nn.Conv2d(num_features + feat_out_channels[3], num_features, 3, 1, 1, bias=False),
+                                         nn.ELU())
+        self.upconv4 = upconv(num_features, num_features // 2)
+        self.bn4 = nn.BatchNorm2d(num_features // 2, momentum=0.01, affine=True, eps=1.1e-5)
+        self.conv4 = torch.nn.Sequential(nn.Conv2d(num_features // 2 + feat_out_channels[2], num_features // 2, 3, 1, 1, bias=False),
+                                         nn.ELU())
+        self.bn4_2 = nn.BatchNorm2d(num_features // 2, momentum=0.01, affine=True, eps=1.1e-5)
+
+        self.daspp_3 = atrous_conv(num_features // 2, num_features // 4, 3, apply_bn_first=False)
+        self.daspp_6 = atrous_conv(num_features // 2 + num_features // 4 + feat_out_channels[2], num_features // 4, 6)
+        self.daspp_12 = atrous_conv(num_features + feat_out_channels[2], num_features // 4, 12)
+        self.daspp_18 = atrous_conv(num_features + num_features // 4 + feat_out_channels[2], num_features // 4, 18)
+        self.daspp_24 = atrous_conv(num_features + num_features // 2 + feat_out_channels[2], num_features // 4, 24)
+        self.daspp_conv = torch.nn.Sequential(nn.Conv2d(num_features + num_features // 2 + num_features // 4, num_features // 4, 3, 1, 1, bias=False),
+                                              nn.ELU())
+        self.reduc8x8 = reduction_1x1(num_features // 4, num_features // 4, self.params.max_depth)
+        self.lpg8x8 = local_planar_guidance(8)
+
+        self.upconv3 = upconv(num_features // 4, num_features // 4)
+        self.bn3 = nn.BatchNorm2d(num_features // 4, momentum=0.01, affine=True, eps=1.1e-5)
+        self.conv3 = torch.nn.Sequential(nn.Conv2d(num_features // 4 + feat_out_channels[1] + 1, num_features // 4, 3, 1, 1, bias=False),
+                                         nn.ELU())
+        self.reduc4x4 = reduction_1x1(num_features // 4, num_features // 8, self.params.max_depth)
+        self.lpg4x4 = local_planar_guidance(4)
+
+        self.upconv2 = upconv(num_features // 4, num_features // 8)
+        self.bn2 = nn.BatchNorm2d(num_features // 8, momentum=0.01, affine=True, eps=1.1e-5)
+        self.conv2 = torch.nn.Sequential(nn.Conv2d(num_features // 8 + feat_out_channels[0] + 1, num_features // 8, 3, 1, 1, bias=False),
+                                         nn.ELU())
+
+        self.reduc2x2 = reduction_1x1(num_features // 8, num_features // 16, self.params.max_depth)
+        self.lpg2x2 = local_planar_guidance(2)
+
+        self.upconv1 = upconv(num_features // 8, num_features // 16)
+        self.reduc1x1 = reduction_1x1(num_features // 16, num_features // 32, self.params.max_depth, is_final=True)
+        self.conv1 = torch.nn.Sequential(nn.Conv2d(num_features // 16 + 4, num_features // 16, 3, 1, 1, bias=False),
+                                         nn.ELU())
+        self.get_depth = torch.nn.Sequential(nn.Conv2d(num_features // 16, 1, 3, 1, 1, bias=False),
+                                             nn.Sigmoid())
+        self._pack = None
+        self._pack_key = None
+        self._bufs: Dict[tuple, Dict[str, torch.Tensor]] = {}
+
+    # ------------------------------------------------------------------ weight packing (lazy)
+    def packed(self):
+        own = [self.bn5, self.conv5, self.bn4, self.conv4, self.bn4_2, self.daspp_conv, self.bn3, self.conv3,
+               self.bn2, self.conv2, self.conv1, self.get_depth]
+        key = tuple(_param_key(m) for m in own)
+        if self._pack is not None and self._pack_key == key:
+            return self._pack
+        nf = self.num_features
+        f = self.feat_out_channels
+        P = {}
+        P["conv5"] = ops.pack_conv_weight(self.conv5[0].weight.detach())
+        P["conv4"] = ops.pack_conv_weight(self.conv4[0].weight.detach())
+        # daspp_conv reads buffer order [d3,d6,d12,d18,d24,iconv4]; reference order is [iconv4,d3,...] (bts.py:246)
+        n_d = 5 * (nf // 4)
+        perm = torch.cat([torch.arange(nf // 2, nf // 2 + n_d), torch.arange(0, nf // 2)])
+        P["daspp_conv"] = ops.pack_conv_weight(self.daspp_conv[0].weight.detach(), perm=perm)
+        P["conv3"] = ops.pack_conv_weight(self.conv3[0].weight.detach())
+        P["conv2"] = ops.pack_conv_weight(self.conv2[0].weight.detach())
+        P["conv1"] = ops.pack_conv_weight(self.conv1[0].weight.detach())
+        P["bn5"] = _bn_vecs(self.bn5, ops.round_up(nf, 32))
+        P["bn4"] = _bn_vecs(self.bn4, ops.round_up(nf // 2, 32))
+        P["bn4_2"] = _bn_vecs(self.bn4_2, ops.round_up(nf // 2, 32))
+        P["bn3"] = _bn_vecs(self.bn3, ops.round_up(nf // 4, 32))
+        P["bn2"] = _bn_vecs(self.bn2, ops.round_up(nf // 8, 32))
+        P["get_depth"] = self.get_depth[0].weight.detach().float().contiguous()
+        self._pack, self._pack_key = P, key
+        return P
+
+    # ------------------------------------------------------------------ NHWC workspace (per shape)
+    def _workspace(self, B: int, H: int, W: int, device) -> Dict[str, torch.Tensor]:
+        key = (B, H, W, str(device))
+        ws = self._bufs.get(key)
+        if ws is not None:
+            return ws
+        nf, f = self.num_features, self.feat_out_channels
+        n32, n16, n8, n4, n2, n1 = [B * (H // s) * (W // s) for s in (32, 16, 8, 4, 2, 1)]
+
+        def z(n, c):
+            return torch.zeros((n, c), dtype=torch.float32, device=device)
+
+        r4 = ops.round_up
+        ws = dict(
+            f5=z(n32, r4(f[4], 4)),
+            cat5=z(n16, r4(nf + f[3], 4)),                       # [upconv5 | skip3]
+            iconv5=z(n16, nf),
+            x8=z(n8, nf // 2 + f[2] + 5 * (nf // 4) + nf // 2),  # [upconv4 | skip2 | d3 d6 d12 d18 d24 | iconv4]
+            mid=z(n8, nf // 2),
+            daspp_feat=z(n8, nf // 4),
+            plane8=z(n8, 4),
+            cat3=z(n4, r4(nf // 4 + f[1] + 1, 4)),               # [upconv3 | skip1 | depth_8x8_scaled_ds | 0-pad]
+            iconv3=z(n4, nf // 4),
+            plane4=z(n4, 4),
+            cat2=z(n2, r4(nf // 8 + f[0] + 1, 4)),               # [upconv2 | skip0 | depth_4x4_scaled_ds | 0-pad]
+            iconv2=z(n2, nf // 8),
+            plane2=z(n2, 4),
+            cat1=z(n1, nf // 16 + 4),                            # [upconv1 | reduc1x1 d2 d4 d8]
+        )
+        if len(self._bufs) >= 4:
+            self._bufs.clear()
+        self._bufs[key] = ws
+        return ws
+
+    def forward(self, features, focal):
+        _require_eval(self, "bts")
+        skip0, skip1, skip2, skip3, dense = features[1], features[2], features[3], features[4], features[5]
+        ops._need(dense, "bts.forward")
+        B = dense.shape[0]
+        H, W = dense.shape[2] * 32, dense.shape[3] * 32
+        dev = dense.device
+        nf, f = self.num_features, self.feat_out_channels
+        md = float(self.params.max_depth)
+        P = self.packed()
+        ws = self._workspace(B, H, W, dev)
+        h16, w16, h8, w8, h4, w4, h2, w2 = H // 16, W // 16, H // 8, W // 8, H // 4, W // 4, H // 2, W // 2
+        ELU = ops.ACT_ELU
+
+        def conv(name_w, x2d, hh, ww, cout, y2d=None, y_nchw=None, up=1, e2=None, c_in_ld=None):
+            wp = P[name_w] if isinstance(name_w, str) else name_w
+            return ops.conv_forward(x2d, B, hh, ww, wp[0], cout, 3, dil=1, up=up, act=ELU, e2=e2, c_in_ld=c_in_ld,
+                                    y2d=y2d, y_nchw=y_nchw)
+
+        # boundary: NCHW encoder taps -> NHWC channel slices (dense_features = ReLU(features[5]), bts.py:225)
+        ops.nchw_to_nhwc(dense, ws["f5"][:, :f[4]], relu=True)
+        ops.nchw_to_nhwc(skip3, ws["cat5"][:, nf:nf + f[3]])
+        ops.nchw_to_nhwc(skip2, ws["x8"][:, nf // 2:nf // 2 + f[2]])
+        ops.nchw_to_nhwc(skip1, ws["cat3"][:, nf // 4:nf // 4 + f[1]])
+        ops.nchw_to_nhwc(skip0, ws["cat2"][:, nf // 8:nf // 8 + f[0]])
+
+        # H/16 and H/8 trunk (bts.py:226-235)
+        conv(self.upconv5.packed(), ws["f5"], H // 32, W // 32, nf, y2d=ws["cat5"][:, :nf], up=2, e2=P["bn5"])
+        conv("conv5", ws["cat5"], h16, w16, nf, y2d=ws["iconv5"])
+        x8 = ws["x8"]
+        c_cat4 = nf // 2 + f[2]
+        o_d = c_cat4                              # first ASPP output slot
+        o_i4 = c_cat4 + 5 * (nf // 4)             # iconv4 slot
+        conv(self.upconv4.packed(), ws["iconv5"], h16, w16, nf // 2, y2d=x8[:, :nf // 2], up=2, e2=P["bn4"])
+        conv("conv4", x8[:, :c_cat4], h8, w8, nf // 2, y2d=x8[:, o_i4:o_i4 + nf // 2], e2=P["bn4_2"])
+
+        # dense ASPP (bts.py:237-247): each branch reads a prefix of x8 and appends its 128 channels
+        q = nf // 4
+        self.daspp_3.run_nhwc(x8[:, o_i4:o_i4 + nf // 2], B, h8, w8, ws["mid"], x8[:, o_d:o_d + q])
+        self.daspp_6.run_nhwc(x8[:, :o_d + q], B, h8, w8, ws["mid"], x8[:, o_d + q:o_d + 2 * q])
+        self.daspp_12.run_nhwc(x8[:, :o_d + 2 * q], B, h8, w8, ws["mid"], x8[:, o_d + 2 * q:o_d + 3 * q])
+        self.daspp_18.run_nhwc(x8[:, :o_d + 3 * q], B, h8, w8, ws["mid"], x8[:, o_d + 3 * q:o_d + 4 * q])
+        self.daspp_24.run_nhwc(x8[:, :o_d + 4 * q], B, h8, w8, ws["mid"], x8[:, o_d + 4 * q:o_d + 5 * q])
+        conv("daspp_conv", x8[:, o_d:], h8, w8, q, y2d=ws["daspp_feat"])
+
+        def am():
+            return torch.empty((), dtype=torch.float32, device=dev)
+
+        # 8x8 scale (bts.py:249-256)
+        self.reduc8x8.run_nhwc(ws["daspp_feat"], ws["plane8"], True)
+        depth_8x8_scaled = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        a8 = am()
+        c3 = ws["cat3"]
+        ops.lpg_fused_forward(ws["plane8"], B, h8, w8, 8, md, False, depth_8x8_scaled,
+                              ds_out=c3[:, q + f[1]], ds_factor=4, ds_pix_stride=c3.stride(0), abs_min=a8)
+        self.lpg8x8.abs_min = a8
+
+        # H/4 (bts.py:258-270)
+        conv(self.upconv3.packed(), ws["daspp_feat"], h8, w8, q, y2d=c3[:, :q], up=2, e2=P["bn3"])
+        conv("conv3", c3, h4, w4, q, y2d=ws["iconv3"])
+        self.reduc4x4.run_nhwc(ws["iconv3"], ws["plane4"], True)
+        depth_4x4_scaled = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        a4 = am()
+        c2 = ws["cat2"]
+        ops.lpg_fused_forward(ws["plane4"], B, h4, w4, 4, md, False, depth_4x4_scaled,
+                              ds_out=c2[:, nf // 8 + f[0]], ds_factor=2, ds_pix_stride=c2.stride(0), abs_min=a4)
+        self.lpg4x4.abs_min = a4
+
+        # H/2 (bts.py:272-283)
+        conv(self.upconv2.packed(), ws["iconv3"], h4, w4, nf // 8, y2d=c2[:, :nf // 8], up=2, e2=P["bn2"])
+        conv("conv2", c2, h2, w2, nf // 8, y2d=ws["iconv2"])
+        self.reduc2x2.run_nhwc(ws["iconv2"], ws["plane2"], True)
+        depth_2x2_scaled = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        a2 = am()
+        ops.lpg_fused_forward(ws["plane2"], B, h2, w2, 2, md, False, depth_2x2_scaled, abs_min=a2)
+        self.lpg2x2.abs_min = a2
+
+        # full resolution (bts.py:285-291)
+        c1 = ws["cat1"]
+        n16c = nf // 16
+        conv(self.upconv1.packed(), ws["iconv2"], h2, w2, n16c, y2d=c1[:, :n16c], up=2)
+        reduc1x1 = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        self.reduc1x1.run_nhwc(c1[:, :n16c], reduc1x1, False)
+        ops.pack_planes([reduc1x1, depth_2x2_scaled, depth_4x4_scaled, depth_8x8_scaled], c1[:, n16c:n16c + 4])
+        iconv1 = torch.empty((B, n16c, H, W), dtype=torch.float32, device=dev)
+        conv("conv1", c1, H, W, n16c, y_nchw=iconv1)
+        fo = None
+        if self.params.dataset == 'kitti':
+            fo = focal.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        final_depth = ops.get_depth_forward(iconv1, P["get_depth"], md, fo)
+
+        return depth_8x8_scaled, depth_4x4_scaled, depth_2x2_scaled, reduc1x1, final_depth, iconv1
+
+
+class encoder(nn.Module):
+    """bts.py:295-338.  Same ``base_model`` tree / tap names; weights come from the checkpoint
+    (``pretrained=True`` needs the network and torchvision, neither available here)."""
+
+    def __init__(self, params):
+        super(encoder, self).__init__()
+        self.params = params
+        self.base_model = build_base_model(params.encoder)
+        if 'densenet' in params.encoder:
+            self.feat_names = ['relu0', 'pool0', 'transition1', 'transition2', 'norm5']
+            self.feat_out_channels = {'densenet121_bts': [64, 64, 128, 256, 1024],
+                                      'densenet161_bts': [96, 96, 192, 384, 2208]}[params.encoder]
+        else:
+            self.feat_names = ['relu', 'layer1', 'layer2', 'layer3', 'layer4']
+            self.feat_out_channels = [64, 256, 512, 1024, 2048]
+
+    def forward(self, x):
+        features = [x]
+        skip_feat = [x]
+        for k, v in self.base_model._modules.items():
+            if 'fc' in k or 'avgpool' in k:
+                continue
+            feature = v(features[-1])
+            features.append(feature)
+            if any(x in k for x in self.feat_names):
+                skip_feat.append(feature)
+        return skip_feat
+
+
+class BtsModel(nn.Module):
+    """bts.py:341-349."""
+
+    def __init__(self, params):
+        super(BtsModel, self).__init__()
+        self.encoder = encoder(params)
+        self.decoder = bts(params, self.encoder.feat_out_channels, params.bts_size)
+
+    def forward(self, x, focal):
+        skip_feat = self.encoder(x)
+        return self.decoder(skip_feat, focal)

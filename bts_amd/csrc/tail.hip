@@ -1,0 +1,112 @@
+// The full-resolution tail of the decoder (reference pytorch/bts.py:286-291): concat1 assembly
+// and get_depth (conv3x3 C->1 + sigmoid + max_depth/focal scaling).  Both are HBM-bound: a 1-output
+// convolution has no GEMM shape worth an MFMA tile, so get_depth is a VALU stencil that reads the
+// NCHW iconv1 planes (coalesced along x) exactly once from HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+namespace {
+
+template <int N>
+__global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                          const float* __restrict__ p2, const float* __restrict__ p3,
+                                                          long npix, float* __restrict__ dst, long stride) {
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        float* d = dst + p * stride;
+        if (N == 4) {
+            *reinterpret_cast<float4*>(d) = make_float4(p0[p], p1[p], p2[p], p3[p]);
+        } else {
+            d[0] = p0[p];
+            if (N > 1) d[1] = p1[p];
+            if (N > 2) d[2] = p2[p];
+        }
+    }
+}
+
+// Each thread: 4 adjacent output pixels of one row.  Per channel it needs rows y-1..y+1, columns
+// x0-1..x0+4: one aligned float4 + two edge scalars per row.
+template <int C>
+__global__ __launch_bounds__(256) void get_depth_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                        int B, int H, int W, float max_depth,
+                                                        const float* __restrict__ focal, float* __restrict__ out) {
+    __shared__ float ws[C * 9];
+    for (int i = threadIdx.x; i < C * 9; i += blockDim.x) ws[i] = w[i];
+    __syncthreads();
+    const int W4 = W >> 2;
+    const long total = (long)B * H * W4;
+    const long HW = (long)H * W;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int x0 = (int)(t % W4) * 4;
+        const long rb = t / W4;
+        const int y = (int)(rb % H);
+        const int b = (int)(rb / H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* base = in + (long)b * C * HW;
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            const float* pc = base + (long)c * HW;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y + dy - 1;
+                if (yy < 0 || yy >= H) continue;
+                const float* row = pc + (long)yy * W + x0;
+                const float4 m = *reinterpret_cast<const float4*>(row);
+                const float l = x0 > 0 ? row[-1] : 0.f;
+                const float r = x0 + 4 < W ? row[4] : 0.f;
+                const float k0 = ws[c * 9 + dy * 3 + 0], k1 = ws[c * 9 + dy * 3 + 1], k2 = ws[c * 9 + dy * 3 + 2];
+                acc[0] += l * k0 + m.x * k1 + m.y * k2;
+                acc[1] += m.x * k0 + m.y * k1 + m.z * k2;
+                acc[2] += m.y * k0 + m.z * k1 + m.w * k2;
+                acc[3] += m.z * k0 + m.w * k1 + r * k2;
+            }
+        }
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = max_depth * sigmoid1(acc[i]);                       // bts.py:289
+            if (focal != nullptr) v = v * focal[b] / 715.0873f;           // bts.py:291
+            o[i] = v;
+        }
+        *reinterpret_cast<float4*>(out + ((long)b * H + y) * W + x0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+}  // namespace
+
+extern "C" int bts_pack_planes_f32(const float* p0, const float* p1, const float* p2, const float* p3, int n_planes,
+                                   long npix, float* dst, long dst_pix_stride, bts_stream_t stream) {
+    if (!p0 || !dst || npix <= 0 || n_planes < 1 || n_planes > 4 || dst_pix_stride < n_planes) return BTS_ERR_INVALID;
+    if ((n_planes > 1 && !p1) || (n_planes > 2 && !p2) || (n_planes > 3 && !p3)) return BTS_ERR_INVALID;
+    if (n_planes == 4 && (((uintptr_t)dst & 15) || (dst_pix_stride & 3))) return BTS_ERR_INVALID;
+    long blocks = (npix + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g((unsigned)blocks), b(256);
+    switch (n_planes) {
+        case 1: hipLaunchKernelGGL(pack_planes_kernel<1>, g, b, 0, s, p0, p1, p2, p3, npix, dst, dst_pix_stride); break;
+        case 2: hipLaunchKernelGGL(pack_planes_kernel<2>, g, b, 0, s, p0, p1, p2, p3, npix, dst, dst_pix_stride); break;
+        case 3: hipLaunchKernelGGL(pack_planes_kernel<3>, g, b, 0, s, p0, p1, p2, p3, npix, dst, dst_pix_stride); break;
+        default: hipLaunchKernelGGL(pack_planes_kernel<4>, g, b, 0, s, p0, p1, p2, p3, npix, dst, dst_pix_stride); break;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int bts_get_depth_f32(const float* iconv1, const float* w, int B, int C, int H, int W, float max_depth,
+                                 const float* focal, float* final_depth, bts_stream_t stream) {
+    if (!iconv1 || !w || !final_depth || B <= 0 || H <= 0 || W <= 0) return BTS_ERR_INVALID;
+    if ((W & 3) || ((uintptr_t)iconv1 & 15) || ((uintptr_t)final_depth & 15)) return BTS_ERR_UNSUPPORTED;
+    const long total = (long)B * H * (W / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 32)
+        hipLaunchKernelGGL(get_depth_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, iconv1, w, B, H, W, max_depth,
+                           focal, final_depth);
+    else if (C == 16)
+        hipLaunchKernelGGL(get_depth_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, iconv1, w, B, H, W, max_depth,
+                           focal, final_depth);
+    else
+        return BTS_ERR_UNSUPPORTED;
+    return (int)hipGetLastError();
+}

@@ -240,3 +240,42 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         rc = _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d))
     _lib.check(rc, "bts_conv_fwd_f32")
     return out
+
+
+# ------------------------------------------------------------------------------ tail
+def pack_planes(planes: Sequence[torch.Tensor], dst2d: torch.Tensor):
+    """Interleave 1-channel maps ([B,1,H,W] contiguous each) into dst2d [npix, n] (an NHWC slice)."""
+    stride, n = _rows2d(dst2d, "pack_planes")
+    if n != len(planes) or not 1 <= n <= 4:
+        raise BtsHipError("pack_planes: need 1..4 planes matching the destination slice")
+    npix = dst2d.shape[0]
+    for p in planes:
+        _need(p, "pack_planes")
+        if p.numel() != npix or not p.is_contiguous():
+            raise BtsHipError("pack_planes: plane size mismatch")
+    ptrs = [_ptr(p) for p in planes] + [C.c_void_p(0)] * (4 - n)
+    with torch.cuda.device(dst2d.device):
+        rc = _lib.load().bts_pack_planes_f32(ptrs[0], ptrs[1], ptrs[2], ptrs[3], n, npix, _ptr(dst2d), stride,
+                                             _stream(dst2d))
+    _lib.check(rc, "bts_pack_planes_f32")
+    return dst2d
+
+
+def get_depth_forward(iconv1: torch.Tensor, weight: torch.Tensor, max_depth: float,
+                      focal: Optional[torch.Tensor]) -> torch.Tensor:
+    """get_depth + scaling (reference bts.py:289-291): iconv1 [B,C,H,W] NCHW -> final_depth [B,1,H,W]."""
+    _need(iconv1, "get_depth_forward")
+    _need(weight, "get_depth_forward")
+    B, Cc, H, W = iconv1.shape
+    if not iconv1.is_contiguous() or tuple(weight.shape) != (1, Cc, 3, 3) or not weight.is_contiguous():
+        raise BtsHipError("get_depth_forward: need contiguous iconv1 [B,C,H,W] and weight [1,C,3,3]")
+    if focal is not None:
+        _need(focal, "get_depth_forward")
+        if focal.numel() != B or not focal.is_contiguous():
+            raise BtsHipError("get_depth_forward: focal must be [B]")
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=iconv1.device)
+    with torch.cuda.device(iconv1.device):
+        rc = _lib.load().bts_get_depth_f32(_ptr(iconv1), _ptr(weight), B, Cc, H, W, float(max_depth), _ptr(focal),
+                                           _ptr(out), _stream(iconv1))
+    _lib.check(rc, "bts_get_depth_f32")
+    return out

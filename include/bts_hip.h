@@ -127,6 +127,22 @@ int bts_nchw_to_nhwc_f32(const float* src, int B, int C, long HW, float* dst, lo
 int bts_nhwc_to_nchw_f32(const float* src, long src_pix_stride, int B, int C, long HW, float* dst,
                          bts_stream_t stream);
 
+/* Interleave up to four 1-channel planes ([npix] each, e.g. reduc1x1 and the three LPG depth maps)
+ * into consecutive channels of an NHWC buffer: dst[p*dst_pix_stride + i] = plane_i[p].
+ * Builds the tail of concat1 = cat[upconv1, reduc1x1, depth_2x2, depth_4x4, depth_8x8]
+ * (pytorch/bts.py:287) without a torch.cat pass.  Unused planes = NULL (n_planes 1..4).
+ */
+int bts_pack_planes_f32(const float* p0, const float* p1, const float* p2, const float* p3, int n_planes,
+                        long npix, float* dst, long dst_pix_stride, bts_stream_t stream);
+
+/* get_depth + final scaling (pytorch/bts.py:220-221, 289-291):
+ *   final_depth[b,0,y,x] = max_depth * sigmoid( conv3x3(iconv1, w)[b,0,y,x] ) [* focal[b] / 715.0873]
+ *   iconv1 : [B,C,H,W] NCHW (the tensor bts.forward returns), w : [1,C,3,3] as stored in the
+ *   state dict (get_depth.0.weight), focal : [B] or NULL (non-KITTI datasets skip the focal term).
+ */
+int bts_get_depth_f32(const float* iconv1, const float* w, int B, int C, int H, int W, float max_depth,
+                      const float* focal, float* final_depth, bts_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+"""CPU: host-side logic -- state_dict compatibility with the reference, C-ABI export list, loud failure
+without a GPU, weight packing layouts."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from bts_amd import synth
+from parity_util import Params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "bts_hip.h")).read()
+    declared = set(re.findall(r"\b(bts_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("bts_conv_desc")
+    lib = ctypes.CDLL(os.path.join(ROOT, "bts_amd", "libbts_hip.so"))
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "include/bts_hip.h declares %s but libbts_hip.so does not export it" % sym
+    from bts_amd import _lib
+    assert set(_lib.SYMBOLS) == declared
+    lib.bts_hip_abi_version.restype = ctypes.c_int
+    assert lib.bts_hip_abi_version() == 1
+
+
+def test_conv_desc_layout_matches_header():
+    from bts_amd._lib import ConvDesc
+    assert ctypes.sizeof(ConvDesc) == 152
+    assert ConvDesc.w.offset == 48 and ConvDesc.y.offset == 128 and ConvDesc.y_nchw.offset == 144
+
+
+@pytest.mark.parametrize("enc", ["densenet161_bts", "resnext101_bts", "densenet121_bts", "resnet50_bts"])
+def test_decoder_state_dict_matches_reference_keys(enc):
+    """Keys/shapes of the reference decoder (dumped from the import, see gen_golden.py strict load) ==
+    synth.decoder_param_shapes == the product module's state_dict."""
+    from bts_amd import bts as M
+    feat = synth.ENCODER_CHANNELS[enc]
+    dec = M.bts(Params(enc, 512, 80.0, "kitti"), feat, 512)
+    sd = dec.state_dict()
+    shapes = synth.decoder_param_shapes(feat, 512)
+    assert list(sd.keys()) == list(shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    if enc == "densenet161_bts":
+        assert len(sd) == 110
+        assert tuple(sd["daspp_6.atrous_conv.first_bn.weight"].shape) == (576,)
+        assert tuple(sd["reduc8x8.reduc.inter_128_64.0.weight"].shape) == (64, 128, 1, 1)
+        assert tuple(sd["reduc1x1.reduc.final.0.weight"].shape) == (1, 8, 1, 1)
+        assert tuple(sd["upconv5.conv.weight"].shape) == (512, 2208, 3, 3)
+
+
+def test_btsmodel_tree_and_encoder_taps():
+    """BtsModel(params) attribute tree (encoder / decoder / decoder.lpg*.abs_min) and the encoder's tap
+    shapes (bts.py:327-338), on CPU (the encoder is plain torch)."""
+    from bts_amd import bts as M
+    m = M.BtsModel(Params("densenet161_bts", 512, 80.0, "kitti")).eval()
+    assert m.decoder.lpg8x8.abs_min is None
+    keys = list(m.state_dict().keys())
+    assert keys[0] == "encoder.base_model.conv0.weight"
+    assert "encoder.base_model.denseblock3.denselayer36.conv2.weight" in keys
+    assert "encoder.base_model.transition2.norm.running_var" in keys
+    assert "decoder.get_depth.0.weight" in keys
+    n_params = sum(p.numel() for p in m.parameters())
+    assert abs(n_params - 47.0e6) < 0.5e6          # reference README: DenseNet161 BTS 47.0 M
+    with torch.no_grad():
+        taps = m.encoder(torch.zeros(1, 3, 64, 96))
+    assert [tuple(t.shape[1:]) for t in taps[1:]] == [(96, 32, 48), (96, 16, 24), (192, 8, 12), (384, 4, 6), (2208, 2, 3)]
+    r = M.BtsModel(Params("resnext101_bts", 512, 10.0, "nyu")).eval()
+    assert "encoder.base_model.layer3.22.conv2.weight" in r.state_dict()
+    assert tuple(r.state_dict()["encoder.base_model.layer1.0.conv2.weight"].shape) == (256, 8, 3, 3)
+    assert abs(sum(p.numel() for p in r.parameters()) - 112.8e6) < 1.5e6   # README: 112.8 M
+    with torch.no_grad():
+        taps = r.encoder(torch.zeros(1, 3, 64, 64))
+    assert [t.shape[1] for t in taps[1:]] == [64, 256, 512, 1024, 2048]
+
+
+def test_hot_path_fails_loudly_without_gpu():
+    from bts_amd import bts as M, ops
+    from bts_amd._lib import BtsHipError
+    with pytest.raises(BtsHipError):
+        ops.lpg_forward(torch.zeros(1, 4, 2, 2), 2)
+    dec = M.bts(Params("densenet161_bts", 512, 80.0, "kitti"), synth.ENCODER_CHANNELS["densenet161_bts"], 512).eval()
+    feats = [None] + [torch.from_numpy(f) for f in synth.encoder_features(synth.ENCODER_CHANNELS["densenet161_bts"], 1, 32, 32)[1:]]
+    with pytest.raises(BtsHipError):
+        dec(feats, torch.ones(1))
+
+
+def test_pack_layouts():
+    from bts_amd import ops
+    w = torch.arange(2 * 5 * 9, dtype=torch.float32).reshape(2, 5, 3, 3)
+    p, cop, kp = ops.pack_conv_weight(w)
+    assert (cop, kp) == (32, 32) and tuple(p.shape) == (9, 32, 32)
+    assert p[4, 1, 3] == w[1, 3, 1, 1] and p[0, 0, 0] == w[0, 0, 0, 0] and p[8, 1, 4] == w[1, 4, 2, 2]
+    assert p[:, 2:, :].abs().sum() == 0 and p[:, :, 5:].abs().sum() == 0
+    perm = torch.tensor([4, 0, 1, 2, 3])
+    pp, _, _ = ops.pack_conv_weight(w, perm=perm)
+    assert pp[4, 1, 0] == w[1, 4, 1, 1]
+    # reduction fragments: float4 ((mt*(K/8)+g)*64 + 32h + i) = W[32mt+i][4(2g+h) .. +3]
+    w1 = torch.arange(16 * 32, dtype=torch.float32).reshape(16, 32, 1, 1)
+    f = ops.pack_reduc_weights([w1]).view(-1, 4)
+    K = 32
+    for (mt, g, h, i) in ((0, 0, 0, 0), (0, 1, 1, 5), (0, 3, 0, 15), (0, 2, 1, 20)):
+        got = f[(mt * (K // 8) + g) * 64 + 32 * h + i]
+        exp = w1[i, 4 * (2 * g + h):4 * (2 * g + h) + 4, 0, 0] if i < 16 else torch.zeros(4)
+        assert torch.equal(got, exp)
+    assert ops.reduc_chain(128, 128) == [(128, 128), (128, 64), (64, 32), (32, 16), (16, 8), (8, -1)]
+    assert synth.reduc_chain_channels(32, 16, True) == [32, 16, 8, 1]
