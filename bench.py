@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Headline benchmark: depth frames/s of BtsModel.forward (DenseNet161 encoder on PyTorch-ROCm + the
+all-HIP decoder hot path) at B=16 per GPU, 3x352x1216 fp32 synthetic KITTI-shape input
+(BASELINE.json configs[1]); weak scaling over N GPUs (one process per GPU, RCCL).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant hand-written
+kernel, HIP-event timed on its launch stream) and `cpu_baseline` (the CPU oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import namedtuple
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # encoder convs (MIOpen): no exhaustive search on a fresh box
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+Params = namedtuple("Params", "encoder bts_size max_depth dataset")
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32-input peak
+PEAK_HBM_GBS = 8000.0
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line is the only thing on stdout)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %6.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def build_model(params, device, seed=0):
+    """Random-init encoder (kaiming) + PCG64(seed) synthetic decoder state (bts_amd.synth)."""
+    from bts_amd import bts as M, synth
+    torch.manual_seed(seed)
+    model = M.BtsModel(params)
+    feat = synth.ENCODER_CHANNELS[params.encoder]
+    sd = {k: (torch.tensor(v) if np.ndim(v) == 0 else torch.from_numpy(v.copy()))
+          for k, v in synth.decoder_state(feat, params.bts_size, seed).items()}
+    model.decoder.load_state_dict(sd, strict=True)
+    # keep random-init encoder activations O(1): eval-BN with unit stats does not renormalise 160 layers
+    return model.eval().to(device)
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box
+    exposes all host cores to os.cpu_count() but grants a 1-GPU job a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(params, H, W, seconds_budget=25.0):
+    """The oracle (CPU restatement, oracle/bts_oracle.py) + the same torch encoder on the host cores.
+    Bounded sample: B=1 frames of the same 352x1216 workload until ~seconds_budget is spent."""
+    from bts_amd import bts as M, synth
+    from oracle import bts_oracle as O
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log("cpu baseline on %d threads (os.cpu_count()=%s)" % (cores, os.cpu_count()))
+    torch.manual_seed(0)
+    enc = M.encoder(params).eval()
+    state = O.state_from_numpy(synth.decoder_state(synth.ENCODER_CHANNELS[params.encoder], params.bts_size, 0))
+    img = torch.from_numpy(synth.image_batch(1, H, W, 1234))
+    focal = torch.from_numpy(synth.focal_values(1, params.dataset, 1234))
+    times = []
+    with torch.no_grad():
+        t_all = time.perf_counter()
+        for i in range(8):
+            t0 = time.perf_counter()
+            feats = enc(img)
+            O.decoder_forward(state, feats, focal, params.max_depth, params.dataset)
+            dt = time.perf_counter() - t0
+            log("cpu frame %d: %.2f s" % (i, dt))
+            if i > 0:
+                times.append(dt)
+            if time.perf_counter() - t_all > seconds_budget and len(times) >= 2:
+                break
+    med = float(np.median(times))
+    return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "B=1 x %d timed frames (1 warm-up) of the same 3x%dx%d fp32 workload, torch %s CPU encoder + "
+                      "oracle decoder, median" % (len(times), H, W, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU (weak scaling)")
+    ap.add_argument("--height", type=int, default=352)
+    ap.add_argument("--width", type=int, default=1216)
+    ap.add_argument("--encoder", default="densenet161_bts")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the per-step all-gather of the 5 depth maps (N>1)")
+    ap.add_argument("--decoder-only", action="store_true", help="time only the decoder hot path on encoder-shaped features")
+    ap.add_argument("--miopen", action="store_true",
+                    help="let the torch encoder use MIOpen (this image has no gfx950 find-db: the first pass JIT-compiles "
+                         "~160 conv configs for >7 min); default runs the encoder on ATen's native conv path")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.enabled = bool(args.miopen)
+
+    from bts_amd import dist as bdist, ops, synth
+    is_kitti = True
+    params = Params(args.encoder, 512, 80.0 if is_kitti else 10.0, "kitti" if is_kitti else "nyu")
+    B, H, W = args.batch, args.height, args.width
+    log("building model %s" % args.encoder)
+    model = build_model(params, device, seed=0)
+    bdist.broadcast_module(model, src=0)            # RCCL broadcast of ~188 MB, once
+    log("model on %s" % device)
+
+    image = torch.from_numpy(synth.image_batch(B, H, W, 1234 + rank)).to(device)
+    focal = torch.from_numpy(synth.focal_values(B, params.dataset, 1234 + rank)).to(device)
+    feats_static = None
+    if args.decoder_only:
+        fe = synth.encoder_features(synth.ENCODER_CHANNELS[args.encoder], B, H, W, 1234 + rank)
+        feats_static = [None] + [torch.from_numpy(f).to(device) for f in fe[1:]]
+
+    def forward():
+        if feats_static is not None:
+            return model.decoder(feats_static, focal)
+        return model(image, focal)
+
+    use_graph = not args.no_graph
+    graph, outs = None, None
+    with torch.no_grad():
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(2):                     # eager passes: MIOpen kernel selection, weight packing, workspaces
+                outs = forward()
+                torch.cuda.synchronize()
+                log("eager pass %d done" % i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if use_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    outs = forward()
+                graph.replay()
+                torch.cuda.synchronize()
+            except Exception as e:                 # report, never hide: the JSON says graph=false
+                if rank == 0:
+                    print("[bench] hipGraph capture failed, running eager: %r" % (e,), file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
+
+        gather = world > 1 and not args.no_gather
+        pending = [None]
+
+        def step():
+            nonlocal outs
+            if graph is not None:
+                graph.replay()
+            else:
+                outs = forward()
+            if gather:
+                if pending[0] is not None:
+                    pending[0][1].wait()
+                pending[0] = bdist.all_gather_depths(outs, 5, async_op=True)
+
+        log("hipgraph=%s; warm-up" % (graph is not None))
+        for _ in range(args.warmup):
+            step()
+        if pending[0] is not None:
+            pending[0][1].wait()
+            pending[0] = None
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if pending[0] is not None:
+            pending[0][1].wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        log("timed %d steps: %.3f ms/step" % (args.steps, 1e3 * elapsed / args.steps))
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+
+        # ---- roofline leg: HIP events around every hand-written launch, eager, on the launch stream
+        roof = None
+        if rank == 0:
+            tr = ops.KernelTrace()
+            ops.set_trace(tr)
+            nrep = max(3, min(args.steps, 10))
+            for _ in range(nrep):
+                forward()
+            ops.set_trace(None)
+            summ = tr.summary()
+            dom = max((k for k in summ if k.startswith("conv_fwd_kernel")), key=lambda k: summ[k]["ms"])
+            d = summ[dom]
+            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            aspp = d["tags"].get("aspp")
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": d["launches"] // nrep,
+                    "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                    "algorithmic_gflop_per_step": round(d["flops"] / nrep / 1e9, 2)}
+            if aspp:
+                a_t = aspp["flops"] / (aspp["ms"] * 1e-3) / 1e12
+                roof["aspp"] = {"launches_per_step": aspp["launches"] // nrep, "ms_per_step": round(aspp["ms"] / nrep, 3),
+                                "gflop_per_step": round(aspp["flops"] / nrep / 1e9, 2), "achieved": round(a_t, 2),
+                                "frac": round(a_t / PEAK_MFMA_F32_TFLOPS, 4)}
+            others = {}
+            for k, v in summ.items():
+                if k == dom:
+                    continue
+                e = {"ms_per_step": round(v["ms"] / nrep, 4), "launches_per_step": v["launches"] // nrep}
+                if k.startswith("conv"):
+                    e["tflops"] = round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)
+                else:
+                    e["gbs"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
+                    e["frac_hbm"] = round(e["gbs"] / PEAK_HBM_GBS, 4)
+                others[k] = e
+            roof["other_kernels"] = others
+            roof["hip_kernels_ms_per_step"] = round(sum(v["ms"] for v in summ.values()) / nrep, 3)
+
+    if rank == 0:
+        fps = world * B * args.steps / elapsed
+        line = {
+            "metric": "depth frames/sec at B=16, 352x1216 KITTI input",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("BTS decoder hot path only" if args.decoder_only else "BtsModel.forward (encoder+decoder)")
+                       + ", %s, B=%d per GPU, 3x%dx%d fp32 (BASELINE.json configs[1])" % (args.encoder, B, H, W),
+                       "batch_per_gpu": B, "global_batch": B * world, "image": "%dx%d" % (H, W),
+                       "parallelism": "dp%d batch-sharded, RCCL weight broadcast once%s" % (
+                           world, ", all-gather of 5 depth maps per step" if gather else ""),
+                       "hipgraph": graph is not None, "encoder_backend": "miopen" if args.miopen else "aten-native",
+                       "weights": "random-init encoder + PCG64(0) synthetic decoder"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle on host cores)")
+            line["cpu_baseline"] = cpu_baseline(params, H, W)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

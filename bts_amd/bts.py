@@ -145,8 +145,8 @@ class atrous_conv(nn.Sequential):
         """Two launches: [BN]+ReLU -> 1x1 -> BN -> ReLU (mid), then dilated 3x3 into the y2d slice."""
         p = self.packed()
         ops.conv_forward(x2d, B, h, w, p["w1"], p["c_mid"], 1, c_in_ld=p["c_in"], pre=p["pre"], pre_relu=True,
-                         e1=p["e1"], act=ops.ACT_RELU, y2d=mid2d)
-        ops.conv_forward(mid2d, B, h, w, p["w2"], p["c_out"], 3, dil=self.dilation, y2d=y2d)
+                         e1=p["e1"], act=ops.ACT_RELU, y2d=mid2d, tag="aspp")
+        ops.conv_forward(mid2d, B, h, w, p["w2"], p["c_out"], 3, dil=self.dilation, y2d=y2d, tag="aspp")
 
     def forward(self, x):
         _require_eval(self, "atrous_conv")
@@ -390,10 +390,10 @@ class bts(nn.Module):
         h16, w16, h8, w8, h4, w4, h2, w2 = H // 16, W // 16, H // 8, W // 8, H // 4, W // 4, H // 2, W // 2
         ELU = ops.ACT_ELU
 
-        def conv(name_w, x2d, hh, ww, cout, y2d=None, y_nchw=None, up=1, e2=None, c_in_ld=None):
+        def conv(name_w, x2d, hh, ww, cout, y2d=None, y_nchw=None, up=1, e2=None, c_in_real=None):
             wp = P[name_w] if isinstance(name_w, str) else name_w
-            return ops.conv_forward(x2d, B, hh, ww, wp[0], cout, 3, dil=1, up=up, act=ELU, e2=e2, c_in_ld=c_in_ld,
-                                    y2d=y2d, y_nchw=y_nchw)
+            return ops.conv_forward(x2d, B, hh, ww, wp[0], cout, 3, dil=1, up=up, act=ELU, e2=e2,
+                                    y2d=y2d, y_nchw=y_nchw, tag="decoder_conv", c_in_real=c_in_real)
 
         # boundary: NCHW encoder taps -> NHWC channel slices (dense_features = ReLU(features[5]), bts.py:225)
         ops.nchw_to_nhwc(dense, ws["f5"][:, :f[4]], relu=True)
@@ -403,8 +403,9 @@ class bts(nn.Module):
         ops.nchw_to_nhwc(skip0, ws["cat2"][:, nf // 8:nf // 8 + f[0]])
 
         # H/16 and H/8 trunk (bts.py:226-235)
-        conv(self.upconv5.packed(), ws["f5"], H // 32, W // 32, nf, y2d=ws["cat5"][:, :nf], up=2, e2=P["bn5"])
-        conv("conv5", ws["cat5"], h16, w16, nf, y2d=ws["iconv5"])
+        conv(self.upconv5.packed(), ws["f5"], H // 32, W // 32, nf, y2d=ws["cat5"][:, :nf], up=2, e2=P["bn5"],
+             c_in_real=f[4])
+        conv("conv5", ws["cat5"], h16, w16, nf, y2d=ws["iconv5"], c_in_real=nf + f[3])
         x8 = ws["x8"]
         c_cat4 = nf // 2 + f[2]
         o_d = c_cat4                              # first ASPP output slot
@@ -435,7 +436,7 @@ class bts(nn.Module):
 
         # H/4 (bts.py:258-270)
         conv(self.upconv3.packed(), ws["daspp_feat"], h8, w8, q, y2d=c3[:, :q], up=2, e2=P["bn3"])
-        conv("conv3", c3, h4, w4, q, y2d=ws["iconv3"])
+        conv("conv3", c3, h4, w4, q, y2d=ws["iconv3"], c_in_real=q + f[1] + 1)
         self.reduc4x4.run_nhwc(ws["iconv3"], ws["plane4"], True)
         depth_4x4_scaled = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
         a4 = am()
@@ -446,7 +447,7 @@ class bts(nn.Module):
 
         # H/2 (bts.py:272-283)
         conv(self.upconv2.packed(), ws["iconv3"], h4, w4, nf // 8, y2d=c2[:, :nf // 8], up=2, e2=P["bn2"])
-        conv("conv2", c2, h2, w2, nf // 8, y2d=ws["iconv2"])
+        conv("conv2", c2, h2, w2, nf // 8, y2d=ws["iconv2"], c_in_real=nf // 8 + f[0] + 1)
         self.reduc2x2.run_nhwc(ws["iconv2"], ws["plane2"], True)
         depth_2x2_scaled = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
         a2 = am()

@@ -16,6 +16,50 @@ from ._lib import BtsHipError, ConvDesc
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 
 
+class KernelTrace:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
+    Each record: (kernel, tag, algorithmic flops, algorithmic bytes, start event, end event)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kern, tag, flops, nbytes, s, e in self.records:
+            d = out.setdefault(kern, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, tags={}))
+            ms = s.elapsed_time(e)
+            d["launches"] += 1
+            d["ms"] += ms
+            d["flops"] += flops
+            d["bytes"] += nbytes
+            t = d["tags"].setdefault(tag, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            t["launches"] += 1
+            t["ms"] += ms
+            t["flops"] += flops
+            t["bytes"] += nbytes
+        return out
+
+
+_trace: Optional[KernelTrace] = None
+
+
+def set_trace(t: Optional[KernelTrace]):
+    global _trace
+    _trace = t
+
+
+def _launch(kern: str, tag: str, flops: float, nbytes: float, fn):
+    if _trace is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = fn()
+    e.record()
+    _trace.records.append((kern, tag, flops, nbytes, s, e))
+    return rc
+
+
 def _stream(t: torch.Tensor):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -66,10 +110,13 @@ def lpg_fused_forward(plane4: torch.Tensor, B: int, h: int, w: int, upratio: int
         raise BtsHipError("lpg_fused_forward: plane4 must be contiguous [B*h*w,4]")
     if depth_scaled.numel() != B * h * k * w * k or not depth_scaled.is_contiguous():
         raise BtsHipError("lpg_fused_forward: depth_scaled must be contiguous [B,1,h*k,w*k]")
+    nbytes = 4.0 * (4 * B * h * w + B * h * k * w * k + (B * h * k * w * k // (ds_factor * ds_factor) if ds_out is not None else 0))
     with torch.cuda.device(plane4.device):
-        rc = _lib.load().bts_lpg_fused_fwd_f32(_ptr(plane4), B, h, w, k, int(bool(normalize)), float(max_depth),
-                                               _ptr(depth_scaled), _ptr(ds_out), int(ds_factor), int(ds_pix_stride),
-                                               _ptr(abs_min), _stream(plane4))
+        rc = _launch("lpg_fwd_kernel<%d,fused>" % k, "lpg", 8.0 * B * h * k * w * k, nbytes,
+                     lambda: _lib.load().bts_lpg_fused_fwd_f32(_ptr(plane4), B, h, w, k, int(bool(normalize)),
+                                                               float(max_depth), _ptr(depth_scaled), _ptr(ds_out),
+                                                               int(ds_factor), int(ds_pix_stride), _ptr(abs_min),
+                                                               _stream(plane4)))
     _lib.check(rc, "bts_lpg_fused_fwd_f32")
     return depth_scaled
 
@@ -117,10 +164,15 @@ def reduc_forward_nhwc(x2d: torch.Tensor, c_in: int, c_first_out: int, w_frag: t
     npix = x2d.shape[0]
     if out.numel() != npix * (1 if is_final else 4) or not out.is_contiguous():
         raise BtsHipError("reduc_forward_nhwc: bad output size")
+    chain = reduc_chain(c_in, c_first_out)
+    macs = sum(ci * (co if co > 0 else (1 if is_final else 3)) for ci, co in chain)
+    nbytes = 4.0 * (npix * (c_in + (1 if is_final else 4)) + macs)
     with torch.cuda.device(x2d.device):
-        rc = _lib.load().bts_reduc_fwd_f32(_ptr(x2d), stride, npix, int(c_in), int(c_first_out), _ptr(w_frag),
-                                           w_frag.numel(), float(max_depth), int(bool(is_final)),
-                                           int(bool(normalize)), _ptr(out), _stream(x2d))
+        rc = _launch("reduc_fwd_kernel<%d,%d>" % (c_in, c_first_out), "reduc", 2.0 * npix * macs, nbytes,
+                     lambda: _lib.load().bts_reduc_fwd_f32(_ptr(x2d), stride, npix, int(c_in), int(c_first_out),
+                                                           _ptr(w_frag), w_frag.numel(), float(max_depth),
+                                                           int(bool(is_final)), int(bool(normalize)), _ptr(out),
+                                                           _stream(x2d)))
     _lib.check(rc, "bts_reduc_fwd_f32")
     return out
 
@@ -191,7 +243,8 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
                  pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_relu: bool = False,
                  e1: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, act: int = ACT_NONE,
                  e2: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                 y2d: Optional[torch.Tensor] = None, y_nchw: Optional[torch.Tensor] = None):
+                 y2d: Optional[torch.Tensor] = None, y_nchw: Optional[torch.Tensor] = None,
+                 tag: str = "conv", c_in_real: Optional[int] = None):
     """One fused convolution (see bts_conv_desc in include/bts_hip.h).
 
     x2d: [B*h_in*w_in, C>=c_in_ld] NHWC view.  Exactly one of y2d ([B*H*W, c_out] NHWC view) /
@@ -236,8 +289,14 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
             raise BtsHipError("conv_forward: y_nchw must be contiguous [B,c_out,H,W]")
         d.y, d.y_pix_stride, d.y_nchw = y_nchw.data_ptr(), 0, 1
         out = y_nchw
+    cin = c_in_real if c_in_real is not None else c_in_ld
+    npix_out = B * H * W
+    flops = 2.0 * npix_out * c_out * cin * taps
+    nbytes = 4.0 * (B * h_in * w_in * cin + npix_out * c_out + taps * c_out * cin)
+    variant = "conv_fwd_kernel<128,%d,%s>" % (128 if (c_out_pad >= 128 or c_out_pad == 96) else (64 if c_out_pad == 64 else 32),
+                                             "nchw" if y_nchw is not None else "nhwc")
     with torch.cuda.device(x2d.device):
-        rc = _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d))
+        rc = _launch(variant, tag, flops, nbytes, lambda: _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d)))
     _lib.check(rc, "bts_conv_fwd_f32")
     return out
 
