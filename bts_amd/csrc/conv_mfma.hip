@@ -50,6 +50,62 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// Issue one K-step's global loads into staging registers.  Everything here is UNCONDITIONAL and
+// branch-free: coordinates are clamped into the image so the address is always valid, and the
+// "was this row real" bit goes to `okmask`; nothing consumes the data until stage_to_lds(), which
+// runs after the MFMA block, so the loads' latency hides under the previous step's MFMAs.
+template <int PA, int PB>
+__device__ __forceinline__ void issue_loads(const ConvArgs& a, int tap, int kc, int lk, const int (&ay)[PA],
+                                            const int (&ax)[PA], const unsigned (&abase)[PA], unsigned avalid,
+                                            const unsigned (&wrow)[PB], f32x4 (&ra)[PA], f32x4 (&rb)[PB],
+                                            f32x4& ps, f32x4& pb, unsigned& okmask) {
+    const int c = kc * BK + lk;
+    const bool cok = c < a.c_in_ld;
+    const int cc = cok ? c : 0;
+    int dy = 0, dx = 0;
+    if (a.ksize == 3) { dy = (tap / 3 - 1) * a.dil; dx = (tap % 3 - 1) * a.dil; }
+    if (a.pre_scale != nullptr) {
+        ps = *reinterpret_cast<const f32x4*>(a.pre_scale + c);
+        pb = *reinterpret_cast<const f32x4*>(a.pre_shift + c);
+    }
+    unsigned m = 0;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int yy = ay[p] + dy, xx = ax[p] + dx;
+        const bool ok = cok && ((avalid >> p) & 1u) && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        const int yc = min(max(yy, 0), a.H - 1) >> a.ups, xc = min(max(xx, 0), a.W - 1) >> a.ups;
+        const unsigned off = (abase[p] + (unsigned)(yc * a.w_in + xc)) * (unsigned)a.x_pix_stride + (unsigned)cc;
+        ra[p] = *reinterpret_cast<const f32x4*>(a.x + off);
+        m |= (ok ? 1u : 0u) << p;
+    }
+    okmask = m;
+    const unsigned wofs = (unsigned)tap * (unsigned)a.c_out_pad * (unsigned)a.k_pad + (unsigned)(kc * BK);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(a.w + (wofs + wrow[p]));
+}
+
+// Prologue (BN affine + ReLU, reference bts.py:70,72) and zero padding, applied on the way to LDS.
+template <int BM, int PA, int PB>
+__device__ __forceinline__ void stage_to_lds(const ConvArgs& a, float* __restrict__ As, int lrow, int lk,
+                                             const f32x4 (&ra)[PA], const f32x4 (&rb)[PB], const f32x4& ps,
+                                             const f32x4& pb, unsigned okmask) {
+    float* Bs = As + BM * LDS_LD;
+    const bool has_pre = a.pre_scale != nullptr;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        f32x4 v = ra[p];
+        if (has_pre) v = v * ps + pb;
+        if (a.pre_relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        const bool ok = (okmask >> p) & 1u;                  // zero padding AFTER the prologue
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        *reinterpret_cast<f32x4*>(As + (p * 32 + lrow) * LDS_LD + lk) = v;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(Bs + (p * 32 + lrow) * LDS_LD + lk) = rb[p];
+}
+
 template <int BM, int BN, int WM, int WN, bool NCHW_OUT>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves");
@@ -73,73 +129,36 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
     const int lrow = tid >> 3, lk = (tid & 7) * 4;
     const int HW = a.H * a.W;
 
-    // per-thread A rows: decode output pixel once
+    // per-thread A rows: decode the output pixel once (host guarantees every element offset < 2^32)
     int ay[PA], ax[PA];
-    long abase[PA];
-    bool aval[PA];
+    unsigned abase[PA], avalid = 0;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
         const long m = m0 + p * 32 + lrow;
-        aval[p] = m < a.M;
-        const long mm = aval[p] ? m : 0;
+        const bool v = m < a.M;
+        avalid |= (v ? 1u : 0u) << p;
+        const long mm = v ? m : 0;
         const int b = (int)(mm / HW);
         const int yx = (int)(mm % HW);
         ay[p] = yx / a.W;
         ax[p] = yx % a.W;
-        abase[p] = (long)b * a.h_in * a.w_in;
+        abase[p] = (unsigned)b * (unsigned)(a.h_in * a.w_in);
+    }
+    unsigned wrow[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        int n = n0 + p * 32 + lrow;
+        n = n < a.c_out_pad ? n : a.c_out_pad - 1;     // rows past c_out_pad feed outputs that are never stored
+        wrow[p] = (unsigned)n * (unsigned)a.k_pad + (unsigned)lk;
     }
 
     const int taps = a.ksize * a.ksize;
     const int kchunks = a.k_pad / BK;
     const int nit = taps * kchunks;
 
-    float4 ra[PA], rb[PB];
-    auto load_global = [&](int tap, int kc) {
-        const int c = kc * BK + lk;
-        const bool cok = c < a.c_in_ld;
-        int dy = 0, dx = 0;
-        if (a.ksize == 3) { dy = (tap / 3 - 1) * a.dil; dx = (tap % 3 - 1) * a.dil; }
-        float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool has_pre = a.pre_scale != nullptr;
-        if (has_pre) {
-            ps = *reinterpret_cast<const float4*>(a.pre_scale + c);
-            pb = *reinterpret_cast<const float4*>(a.pre_shift + c);
-        }
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const int yy = ay[p] + dy, xx = ax[p] + dx;
-            const bool ok = aval[p] && cok && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                const long q = abase[p] + (long)(yy >> a.ups) * a.w_in + (xx >> a.ups);
-                v = *reinterpret_cast<const float4*>(a.x + q * a.x_pix_stride + c);
-                if (has_pre) {
-                    v.x = v.x * ps.x + pb.x; v.y = v.y * ps.y + pb.y;
-                    v.z = v.z * ps.z + pb.z; v.w = v.w * ps.w + pb.w;
-                }
-                if (a.pre_relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-            }
-            ra[p] = v;
-        }
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int n = n0 + p * 32 + lrow;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < a.c_out_pad)
-                v = *reinterpret_cast<const float4*>(a.w + ((long)tap * a.c_out_pad + n) * a.k_pad + kc * BK + lk);
-            rb[p] = v;
-        }
-    };
-    auto store_lds = [&](int buf) {
-        float* As = smem + buf * BUF_FLOATS;
-        float* Bs = As + BM * LDS_LD;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) *reinterpret_cast<float4*>(As + (p * 32 + lrow) * LDS_LD + lk) = ra[p];
-#pragma unroll
-        for (int p = 0; p < PB; ++p) *reinterpret_cast<float4*>(Bs + (p * 32 + lrow) * LDS_LD + lk) = rb[p];
-    };
+    f32x4 ra[PA], rb[PB];
+    f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
+    unsigned okmask = 0;
 
     const int wv = tid >> 6, lane = tid & 63;
     const int wm = wv / WN, wn = wv % WN;
@@ -154,8 +173,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     int tap = 0, kc = 0;
-    load_global(0, 0);
-    store_lds(0);
+    issue_loads<PA, PB>(a, 0, 0, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
+    stage_to_lds<BM, PA, PB>(a, smem, lrow, lk, ra, rb, ps, pb, okmask);
     __syncthreads();
 
     for (int it = 0; it < nit; ++it) {
@@ -163,17 +182,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
         int ntap = tap, nkc = kc + 1;
         if (nkc == kchunks) { nkc = 0; ntap = tap + 1; }
         const bool more = it + 1 < nit;
-        if (more) load_global(ntap, nkc);          // global loads in flight under the MFMAs below
+        if (more) issue_loads<PA, PB>(a, ntap, nkc, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
 
         const float* As = smem + buf * BUF_FLOATS + (wm * TM * 32 + li) * LDS_LD + 4 * lh;
         const float* Bs = smem + buf * BUF_FLOATS + BM * LDS_LD + (wn * TN * 32 + li) * LDS_LD + 4 * lh;
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
-            float4 fa[TM], fb[TN];
+            f32x4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_LD + 8 * g);
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + 8 * g);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_LD + 8 * g);
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + 8 * g);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -191,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
                     }
                 }
         }
-        if (more) store_lds(buf ^ 1);
+        if (more) stage_to_lds<BM, PA, PB>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
         __syncthreads();
         tap = ntap; kc = nkc;
     }
@@ -281,6 +300,9 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if ((d->e1_scale && !d->e1_shift) || (d->e2_scale && !d->e2_shift)) return BTS_ERR_INVALID;
     if (!d->y_nchw && d->y_pix_stride < d->c_out) return BTS_ERR_INVALID;
     if (d->act < 0 || d->act > 3) return BTS_ERR_INVALID;
+    // the kernel addresses both operands with 32-bit element offsets
+    if ((double)d->B * d->h_in * d->w_in * (double)d->x_pix_stride >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
+    if ((double)d->ksize * d->ksize * d->c_out_pad * (double)d->k_pad >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
 
     ConvArgs a;
     a.x = d->x; a.x_pix_stride = d->x_pix_stride; a.c_in_ld = d->c_in_ld; a.k_pad = d->k_pad;
