@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libbts_hip.so")
 SYMBOLS = (
     "bts_hip_abi_version", "bts_hip_error_string", "bts_lpg_fwd_f32", "bts_lpg_fused_fwd_f32",
     "bts_reduc_fwd_f32", "bts_conv_fwd_f32", "bts_nchw_to_nhwc_f32", "bts_nhwc_to_nchw_f32",
-    "bts_pack_planes_f32", "bts_get_depth_f32",
+    "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32",
 )
 
 ABI_VERSION = 1
@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("x_pix_stride", C.c_long), ("c_in_ld", C.c_int), ("k_pad", C.c_int),
         ("B", C.c_int), ("h_in", C.c_int), ("w_in", C.c_int), ("up", C.c_int),
-        ("ksize", C.c_int), ("dil", C.c_int),
+        ("ksize", C.c_int), ("dil", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
         ("w", C.c_void_p), ("c_out", C.c_int), ("c_out_pad", C.c_int),
         ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("pre_relu", C.c_int),
         ("e1_scale", C.c_void_p), ("e1_shift", C.c_void_p), ("act", C.c_int),
@@ -67,6 +67,8 @@ def load():
     lib.bts_reduc_fwd_f32.argtypes = [vp, l, l, i, i, vp, l, f, i, i, vp, vp]
     lib.bts_conv_fwd_f32.restype = i
     lib.bts_conv_fwd_f32.argtypes = [C.POINTER(ConvDesc), vp]
+    lib.bts_conv_plan_f32.restype = i
+    lib.bts_conv_plan_f32.argtypes = [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.bts_nchw_to_nhwc_f32.restype = i
     lib.bts_nchw_to_nhwc_f32.argtypes = [vp, i, i, l, vp, l, i, vp]
     lib.bts_nhwc_to_nchw_f32.restype = i

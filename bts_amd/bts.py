@@ -134,7 +134,7 @@ class atrous_conv(nn.Sequential):
             seq = self.atrous_conv.aconv_sequence
             w1, co1, k1 = ops.pack_conv_weight(seq[1].weight.detach())
             w2, co2, k2 = ops.pack_conv_weight(seq[4].weight.detach())
-            pre = _bn_vecs(self.atrous_conv.first_bn, k1) if self.apply_bn_first else None
+            pre = _bn_vecs(self.atrous_conv.first_bn, k1) if self.apply_bn_first else None   # k1 == c_in_ld
             e1 = _bn_vecs(seq[2], co1)
             self._pack = dict(w1=w1, w2=w2, pre=pre, e1=e1, c_mid=seq[1].out_channels, c_out=seq[4].out_channels,
                               c_in=seq[1].in_channels)

@@ -8,20 +8,22 @@
 // the BN/activation/BN of the OUTPUT is applied on the accumulators (epilogue); concat is
 // free because outputs are written into channel slices of a preallocated NHWC buffer.
 //
-// GEMM view: M = B*H*W output pixels, N = c_out, K = taps * c_in.  Workgroup = 256 threads
+// GEMM view: M = B*H*W output pixels, N = c_out, K = taps * c_in (flattened, tap-major).  Workgroup = 256 threads
 // (4 waves) computing BM x BN with BK = 32 per step.  Both operands are staged K-contiguous
 // in LDS with a 36-float row stride (144 B: the 16 rows a ds_read_b128 lane group touches fall
 // in 16 distinct 16-B bank slots).  A lane reads 4 consecutive k of its row with ONE
 // ds_read_b128 and feeds them to 4 consecutive MFMA k-steps: step q of group g multiplies
 // k = 8g+q (lanes 0-31) and k = 8g+4+q (lanes 32-63) -- the K order is immaterial as long as
-// both operands agree.  3x3 taps are separate K slabs gathered per tap with bounds masks
-// (dilation 24 on a 44-row map leaves no contiguous halo to exploit); zero padding is applied
-// AFTER the prologue, as the reference pads the post-BN-ReLU tensor.
+// both operands agree.  Taps are gathered per lane with bounds masks (dilation 24 on a 44-row
+// map leaves no contiguous halo to exploit); zero padding is applied AFTER the prologue, as the
+// reference pads the post-BN-ReLU tensor.  Stride and a folded nearest-2x upsample live in the
+// gather index, so upconv and the encoder stem need no extra pass.
 //
 // fp32-input MFMA is exact f32 (a k-ordered fmaf chain), so parity with the CPU reference is
 // at rounding-order level (~1e-6), well inside the 1e-3 budget that bf16 operands break.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -30,15 +32,18 @@ constexpr int BK = 32;
 constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
 
 struct ConvArgs {
-    const float* x; long x_pix_stride; int c_in_ld; int k_pad;
+    const float* x; long x_pix_stride; int c_in_ld; int k_pad;   // k_pad: padded flattened K (taps*c_in_ld rounded to 32)
     int B, h_in, w_in, ups;          // ups = log2(up)
-    int ksize, dil;
+    int ksize, dil, stride, pad;
+    int k_flat;                      // ksize*ksize*c_in_ld
+    unsigned magic_c, magic_ks;      // floor(2^32/d)+1 for d = c_in_ld, ksize: exact n/d for n,d < 2^16
     const float* w; int c_out, c_out_pad;
     const float* pre_scale; const float* pre_shift; int pre_relu;
     const float* e1_scale; const float* e1_shift; int act;
     const float* e2_scale; const float* e2_shift;
     float* y; long y_pix_stride;
     int H, W;                        // output spatial size
+    int Hs, Ws;                      // (upsampled) source extent the taps index: h_in*up, w_in*up
     long M;                          // B*H*W
     int n_ntiles;
 };
@@ -55,15 +60,21 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // "was this row real" bit goes to `okmask`; nothing consumes the data until stage_to_lds(), which
 // runs after the MFMA block, so the loads' latency hides under the previous step's MFMAs.
 template <int PA, int PB>
-__device__ __forceinline__ void issue_loads(const ConvArgs& a, int tap, int kc, int lk, const int (&ay)[PA],
+__device__ __forceinline__ void issue_loads(const ConvArgs& a, int it, int lk, const int (&ay)[PA],
                                             const int (&ax)[PA], const unsigned (&abase)[PA], unsigned avalid,
                                             const unsigned (&wrow)[PB], f32x4 (&ra)[PA], f32x4 (&rb)[PB],
                                             f32x4& ps, f32x4& pb, unsigned& okmask) {
-    const int c = kc * BK + lk;
-    const bool cok = c < a.c_in_ld;
-    const int cc = cok ? c : 0;
-    int dy = 0, dx = 0;
-    if (a.ksize == 3) { dy = (tap / 3 - 1) * a.dil; dx = (tap % 3 - 1) * a.dil; }
+    // K is flattened over (tap, channel): k = tap*c_in_ld + c.  A lane's 4 consecutive k never straddle
+    // a tap (c_in_ld % 4 == 0), so each lane decodes its own tap; channel counts that are not multiples
+    // of 32 (36, 164, 228, DenseNet's 48i) then cost no per-tap padding.
+    const unsigned k4 = (unsigned)(it * BK + lk);
+    const bool kok = k4 < (unsigned)a.k_flat;
+    const unsigned kk = kok ? k4 : 0u;
+    const unsigned tap = __umulhi(kk, a.magic_c);
+    const int c = (int)(kk - tap * (unsigned)a.c_in_ld);
+    const int ky = (int)__umulhi(tap, a.magic_ks);
+    const int kx = (int)tap - ky * a.ksize;
+    const int dy = ky * a.dil - a.pad, dx = kx * a.dil - a.pad;
     if (a.pre_scale != nullptr) {
         ps = *reinterpret_cast<const f32x4*>(a.pre_scale + c);
         pb = *reinterpret_cast<const f32x4*>(a.pre_shift + c);
@@ -71,21 +82,21 @@ __device__ __forceinline__ void issue_loads(const ConvArgs& a, int tap, int kc, 
     unsigned m = 0;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int yy = ay[p] + dy, xx = ax[p] + dx;
-        const bool ok = cok && ((avalid >> p) & 1u) && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-        const int yc = min(max(yy, 0), a.H - 1) >> a.ups, xc = min(max(xx, 0), a.W - 1) >> a.ups;
-        const unsigned off = (abase[p] + (unsigned)(yc * a.w_in + xc)) * (unsigned)a.x_pix_stride + (unsigned)cc;
+        const int yy = ay[p] + dy, xx = ax[p] + dx;        // ay/ax already carry the stride
+        const bool ok = kok && ((avalid >> p) & 1u) && (unsigned)yy < (unsigned)a.Hs && (unsigned)xx < (unsigned)a.Ws;
+        const int yc = min(max(yy, 0), a.Hs - 1) >> a.ups, xc = min(max(xx, 0), a.Ws - 1) >> a.ups;
+        const unsigned off = (abase[p] + (unsigned)(yc * a.w_in + xc)) * (unsigned)a.x_pix_stride + (unsigned)c;
         ra[p] = *reinterpret_cast<const f32x4*>(a.x + off);
         m |= (ok ? 1u : 0u) << p;
     }
     okmask = m;
-    const unsigned wofs = (unsigned)tap * (unsigned)a.c_out_pad * (unsigned)a.k_pad + (unsigned)(kc * BK);
+    const unsigned wofs = (unsigned)(it * BK);
 #pragma unroll
     for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(a.w + (wofs + wrow[p]));
 }
 
 // Prologue (BN affine + ReLU, reference bts.py:70,72) and zero padding, applied on the way to LDS.
-template <int BM, int PA, int PB>
+template <int BM, int RPP, int PA, int PB>
 __device__ __forceinline__ void stage_to_lds(const ConvArgs& a, float* __restrict__ As, int lrow, int lk,
                                              const f32x4 (&ra)[PA], const f32x4 (&rb)[PB], const f32x4& ps,
                                              const f32x4& pb, unsigned okmask) {
@@ -100,17 +111,19 @@ __device__ __forceinline__ void stage_to_lds(const ConvArgs& a, float* __restric
         }
         const bool ok = (okmask >> p) & 1u;                  // zero padding AFTER the prologue
         v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-        *reinterpret_cast<f32x4*>(As + (p * 32 + lrow) * LDS_LD + lk) = v;
+        *reinterpret_cast<f32x4*>(As + (p * RPP + lrow) * LDS_LD + lk) = v;
     }
 #pragma unroll
-    for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(Bs + (p * 32 + lrow) * LDS_LD + lk) = rb[p];
+    for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(Bs + (p * RPP + lrow) * LDS_LD + lk) = rb[p];
 }
 
 template <int BM, int BN, int WM, int WN, bool NCHW_OUT>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
-    static_assert(WM * WN == 4, "4 waves");
+__global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a) {
+    constexpr int NT = WM * WN * 64;          // threads per workgroup (4 or 8 waves)
+    constexpr int RPP = NT / 8;               // tile rows staged per pass (8 lanes x 16 B per row)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "tile/wave layout");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     // layout: [buf][A rows BM | B rows BN][LDS_LD]
@@ -134,27 +147,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
     unsigned abase[PA], avalid = 0;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const long m = m0 + p * 32 + lrow;
+        const long m = m0 + p * RPP + lrow;
         const bool v = m < a.M;
         avalid |= (v ? 1u : 0u) << p;
         const long mm = v ? m : 0;
         const int b = (int)(mm / HW);
         const int yx = (int)(mm % HW);
-        ay[p] = yx / a.W;
-        ax[p] = yx % a.W;
+        ay[p] = (yx / a.W) * a.stride;
+        ax[p] = (yx % a.W) * a.stride;
         abase[p] = (unsigned)b * (unsigned)(a.h_in * a.w_in);
     }
     unsigned wrow[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-        int n = n0 + p * 32 + lrow;
+        int n = n0 + p * RPP + lrow;
         n = n < a.c_out_pad ? n : a.c_out_pad - 1;     // rows past c_out_pad feed outputs that are never stored
         wrow[p] = (unsigned)n * (unsigned)a.k_pad + (unsigned)lk;
     }
 
-    const int taps = a.ksize * a.ksize;
-    const int kchunks = a.k_pad / BK;
-    const int nit = taps * kchunks;
+    const int nit = a.k_pad / BK;
 
     f32x4 ra[PA], rb[PB];
     f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
@@ -172,17 +183,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int tap = 0, kc = 0;
-    issue_loads<PA, PB>(a, 0, 0, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
-    stage_to_lds<BM, PA, PB>(a, smem, lrow, lk, ra, rb, ps, pb, okmask);
+    issue_loads<PA, PB>(a, 0, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
+    stage_to_lds<BM, RPP, PA, PB>(a, smem, lrow, lk, ra, rb, ps, pb, okmask);
     __syncthreads();
 
     for (int it = 0; it < nit; ++it) {
         const int buf = it & 1;
-        int ntap = tap, nkc = kc + 1;
-        if (nkc == kchunks) { nkc = 0; ntap = tap + 1; }
         const bool more = it + 1 < nit;
-        if (more) issue_loads<PA, PB>(a, ntap, nkc, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
+        if (more) issue_loads<PA, PB>(a, it + 1, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
 
         const float* As = smem + buf * BUF_FLOATS + (wm * TM * 32 + li) * LDS_LD + 4 * lh;
         const float* Bs = smem + buf * BUF_FLOATS + BM * LDS_LD + (wn * TN * 32 + li) * LDS_LD + 4 * lh;
@@ -193,26 +201,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
             for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + 8 * g);
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + 8 * g);
+            // q outermost: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (NCHW_OUT) {   // rows = out channels, cols (lanes) = pixels
-                        acc[i][j] = mfma32x2(fb[j].x, fa[i].x, acc[i][j]);
-                        acc[i][j] = mfma32x2(fb[j].y, fa[i].y, acc[i][j]);
-                        acc[i][j] = mfma32x2(fb[j].z, fa[i].z, acc[i][j]);
-                        acc[i][j] = mfma32x2(fb[j].w, fa[i].w, acc[i][j]);
-                    } else {          // rows = pixels, cols (lanes) = out channels
-                        acc[i][j] = mfma32x2(fa[i].x, fb[j].x, acc[i][j]);
-                        acc[i][j] = mfma32x2(fa[i].y, fb[j].y, acc[i][j]);
-                        acc[i][j] = mfma32x2(fa[i].z, fb[j].z, acc[i][j]);
-                        acc[i][j] = mfma32x2(fa[i].w, fb[j].w, acc[i][j]);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (NCHW_OUT) acc[i][j] = mfma32x2(fb[j][q], fa[i][q], acc[i][j]);   // rows = channels, lanes = pixels
+                        else          acc[i][j] = mfma32x2(fa[i][q], fb[j][q], acc[i][j]);   // rows = pixels, lanes = channels
                     }
-                }
         }
-        if (more) stage_to_lds<BM, PA, PB>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
+        if (more) stage_to_lds<BM, RPP, PA, PB>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
         __syncthreads();
-        tap = ntap; kc = nkc;
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -271,16 +272,34 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s) {
             e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, a);
     } else {
         auto k = conv_fwd_kernel<BM, BN, WM, WN, false>;
         if (lds > 64 * 1024) {
             e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, a);
     }
     return (int)hipGetLastError();
+}
+
+// Tile choice.  BN follows c_out; BM trades per-tile efficiency against wave quantisation: the chip
+// finishes ceil(n_wg / 256 CUs) "tile rounds", so 836 tiles of 128 rows cost 4 rounds (82 % busy)
+// while 1672 tiles of 64 rows cost 7 half-rounds (93 %).  The 64-row tile pays ~5 % more staging.
+void choose_tile(long M, int c_out_pad, int* bm, int* bn) {
+    *bn = (c_out_pad >= 128 || c_out_pad == 96) ? 128 : (c_out_pad == 64 ? 64 : 32);
+    *bm = 128;
+    if (*bn == 32) return;
+    const long nt = (c_out_pad + *bn - 1) / *bn;
+    const long wg128 = ((M + 127) / 128) * nt, wg64 = ((M + 63) / 64) * nt;
+    const double t128 = (double)((wg128 + 255) / 256) * 128.0;
+    const double t64 = (double)((wg64 + 255) / 256) * 64.0 * 1.05;
+    if (t64 < t128) *bm = 64;
+    if (const char* f = getenv("BTS_CONV_BM")) {       // tuning aid: force the row tile (64 / 128)
+        const int v = atoi(f);
+        if (v == 64 || v == 128) *bm = v;
+    }
 }
 
 }  // namespace
@@ -289,9 +308,12 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if (!d || !d->x || !d->w || !d->y) return BTS_ERR_INVALID;
     if (d->B <= 0 || d->h_in <= 0 || d->w_in <= 0 || d->c_out <= 0) return BTS_ERR_INVALID;
     if (d->up != 1 && d->up != 2) return BTS_ERR_UNSUPPORTED;
-    if (d->ksize != 1 && d->ksize != 3) return BTS_ERR_UNSUPPORTED;
-    if (d->ksize == 3 && d->dil < 1) return BTS_ERR_INVALID;
-    if (d->c_in_ld <= 0 || (d->c_in_ld & 3) || (d->k_pad % BK) || d->k_pad < d->c_in_ld) return BTS_ERR_INVALID;
+    if (d->ksize < 1 || d->ksize > 7 || !(d->ksize & 1)) return BTS_ERR_UNSUPPORTED;
+    if (d->dil < 1 || d->stride < 1 || d->pad < 0) return BTS_ERR_INVALID;
+    if (d->up == 2 && d->stride != 1) return BTS_ERR_UNSUPPORTED;
+    if (d->c_in_ld <= 0 || (d->c_in_ld & 3) || (d->k_pad % BK) || d->k_pad < d->ksize * d->ksize * d->c_in_ld)
+        return BTS_ERR_INVALID;
+    if (d->k_pad >= 65536) return BTS_ERR_UNSUPPORTED;
     if ((d->x_pix_stride & 3) || d->x_pix_stride < d->c_in_ld) return BTS_ERR_INVALID;
     if ((d->c_out_pad & 31) || d->c_out_pad < d->c_out) return BTS_ERR_INVALID;
     if (((uintptr_t)d->x & 15) || ((uintptr_t)d->w & 15)) return BTS_ERR_INVALID;
@@ -302,23 +324,45 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if (d->act < 0 || d->act > 3) return BTS_ERR_INVALID;
     // the kernel addresses both operands with 32-bit element offsets
     if ((double)d->B * d->h_in * d->w_in * (double)d->x_pix_stride >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
-    if ((double)d->ksize * d->ksize * d->c_out_pad * (double)d->k_pad >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
+    if ((double)d->c_out_pad * (double)d->k_pad >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
 
     ConvArgs a;
     a.x = d->x; a.x_pix_stride = d->x_pix_stride; a.c_in_ld = d->c_in_ld; a.k_pad = d->k_pad;
     a.B = d->B; a.h_in = d->h_in; a.w_in = d->w_in; a.ups = d->up == 2 ? 1 : 0;
-    a.ksize = d->ksize; a.dil = d->ksize == 3 ? d->dil : 0;
+    a.ksize = d->ksize; a.dil = d->dil; a.stride = d->stride; a.pad = d->pad;
+    a.k_flat = d->ksize * d->ksize * d->c_in_ld;
+    a.magic_c = (unsigned)(4294967296ULL / (unsigned)d->c_in_ld) + 1u;
+    a.magic_ks = (unsigned)(4294967296ULL / (unsigned)d->ksize) + 1u;
     a.w = d->w; a.c_out = d->c_out; a.c_out_pad = d->c_out_pad;
     a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift; a.pre_relu = d->pre_relu;
     a.e1_scale = d->e1_scale; a.e1_shift = d->e1_shift; a.act = d->act;
     a.e2_scale = d->e2_scale; a.e2_shift = d->e2_shift;
     a.y = d->y; a.y_pix_stride = d->y_pix_stride;
-    a.H = d->h_in * d->up; a.W = d->w_in * d->up;
+    a.Hs = d->h_in * d->up; a.Ws = d->w_in * d->up;
+    a.H = (a.Hs + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
+    a.W = (a.Ws + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
+    if (a.H <= 0 || a.W <= 0) return BTS_ERR_INVALID;
     a.M = (long)d->B * a.H * a.W;
     a.n_ntiles = 0;
     hipStream_t s = (hipStream_t)stream;
     const bool nchw = d->y_nchw != 0;
-    if (d->c_out_pad >= 128 || d->c_out_pad == 96) return launch_conv<128, 128, 2, 2>(a, nchw, s);
-    if (d->c_out_pad == 64) return launch_conv<128, 64, 2, 2>(a, nchw, s);
+    int bm, bn;
+    choose_tile(a.M, d->c_out_pad, &bm, &bn);
+    static const int w8 = getenv("BTS_CONV_W8") ? atoi(getenv("BTS_CONV_W8")) : 0;
+    if (w8) {
+        if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4>(a, nchw, s) : launch_conv<64, 128, 2, 2>(a, nchw, s);
+        if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2>(a, nchw, s) : launch_conv<64, 64, 2, 2>(a, nchw, s);
+    }
+    if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 2>(a, nchw, s) : launch_conv<64, 128, 2, 2>(a, nchw, s);
+    if (bn == 64) return bm == 128 ? launch_conv<128, 64, 2, 2>(a, nchw, s) : launch_conv<64, 64, 2, 2>(a, nchw, s);
     return launch_conv<128, 32, 4, 1>(a, nchw, s);
+}
+
+extern "C" int bts_conv_plan_f32(const bts_conv_desc* d, int* bm, int* bn) {
+    if (!d || !bm || !bn) return BTS_ERR_INVALID;
+    const int Hs = d->h_in * d->up, Ws = d->w_in * d->up;
+    const long H = (Hs + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
+    const long W = (Ws + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
+    choose_tile((long)d->B * H * W, d->c_out_pad, bm, bn);
+    return 0;
 }

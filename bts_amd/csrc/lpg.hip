@@ -33,11 +33,19 @@ __device__ __forceinline__ float lpg_clamp(float d) {
     return d;
 }
 
-// wave-min of |den| then one atomic per wave; abs(den) >= 0 so the uint order is the float order
+// block-min of |den| then ONE atomic per block: same-address atomics serialise in L2 (~12 ns each on
+// MI355X), so the grid is also capped at 1024 blocks.  abs(den) >= 0 so the uint order is the float order.
 __device__ __forceinline__ void publish_abs_min(float m, unsigned* abs_min_bits) {
+    __shared__ float wave_min[4];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMin(abs_min_bits, __float_as_uint(m));
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if ((tid & 63) == 0) wave_min[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        m = fminf(fminf(wave_min[0], wave_min[1]), fminf(wave_min[2], wave_min[3]));
+        atomicMin(abs_min_bits, __float_as_uint(m));
+    }
 }
 
 // K = upratio (1,2,4,8).  PLANAR: input [B,4,h,w]; else cell-interleaved [B*h*w,4].
@@ -50,13 +58,14 @@ __global__ __launch_bounds__(256) void lpg_fwd_kernel(const float* __restrict__ 
                                                       unsigned* __restrict__ abs_min_bits) {
     const int W = w * K, H = h * K;
     const int W4 = W / V;                        // V = 4 when W % 4 == 0 (16-byte stores), else 1
-    const long total = (long)B * H * W4;
+    const int nrows = B * H;
     float amin = __uint_as_float(0x7f800000u);
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(t % W4);
-        const long rb = t / W4;
-        const int r = (int)(rb % H);
-        const int b = (int)(rb / H);
+    // block = 64 x 4: a wave walks one output row in 64-wide strides (coalesced 1 KiB stores), so the
+    // (b, r) decode costs one division per row instead of two per element.
+    for (int row = blockIdx.x * 4 + threadIdx.y; row < nrows; row += gridDim.x * 4)
+    for (int c4 = threadIdx.x; c4 < W4; c4 += 64) {
+        const int r = row % H;
+        const int b = row / H;
         const int cr = r / K;
         const float v = ((float)(r % K) - (float)(K - 1) * 0.5f) / (float)K;   // bts.py:160-161
         float res[V];
@@ -123,10 +132,10 @@ int launch_lpg(const float* plane, int B, int h, int w, int k, int normalize, fl
         if (e != hipSuccess) return (int)e;
     }
     const bool vec4 = (((long)w * k) % 4) == 0;
-    const long total = (long)B * h * k * ((long)w * k / (vec4 ? 4 : 1));
-    long blocks = (total + 255) / 256;
-    if (blocks > 256L * 16) blocks = 256L * 16;      // grid-stride beyond 16 blocks/CU
-    dim3 grid((unsigned)blocks), block(256);
+    if ((long)B * h * k > 0x7fffffffL) return BTS_ERR_UNSUPPORTED;
+    long blocks = ((long)B * h * k + 3) / 4;
+    if (blocks > 1024) blocks = 1024;                // <= 1024 same-address atomics (see publish_abs_min)
+    dim3 grid((unsigned)blocks), block(64, 4);
 #define LPG_LAUNCH(KK)                                                                                          \
     if (vec4)                                                                                                   \
         hipLaunchKernelGGL((lpg_fwd_kernel<KK, 4, PLANAR, FUSED>), grid, block, 0, s, plane, B, h, w, normalize, \

@@ -208,18 +208,27 @@ def round_up(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
-def pack_conv_weight(w: torch.Tensor, perm: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int, int]:
-    """[cout,cin,k,k] -> packed [k*k][cout_pad][k_pad] (tap-major, K-contiguous), zero padded.
+def pack_conv_weight(w: torch.Tensor, perm: Optional[torch.Tensor] = None,
+                     c_in_ld: Optional[int] = None) -> Tuple[torch.Tensor, int, int]:
+    """[cout,cin,k,k] -> packed [cout_pad][k_pad], K flattened tap-major: k = tap*c_in_ld + c, zero padded
+    (c_in_ld = channels the kernel walks per tap, a multiple of 4 >= cin; k_pad = K rounded up to 32).
     ``perm``: optional LongTensor; buffer channel j reads reference input channel perm[j]
-    (lets a concat buffer keep its own channel order).  Returns (packed, cout_pad, k_pad)."""
+    (lets a concat buffer keep its own channel order).  Returns (packed, cout_pad, c_in_ld)."""
     cout, cin, kh, kw = w.shape
     wf = w.float()
     if perm is not None:
         wf = wf[:, perm.to(w.device)]
-    cout_pad, k_pad = round_up(cout, 32), round_up(cin, 32)
-    p = torch.zeros((kh * kw, cout_pad, k_pad), dtype=torch.float32, device=w.device)
-    p[:, :cout, :cin] = wf.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
-    return p.contiguous(), cout_pad, k_pad
+    if c_in_ld is None:
+        c_in_ld = round_up(cin, 4)
+    assert c_in_ld % 4 == 0 and c_in_ld >= cin
+    cout_pad = round_up(cout, 32)
+    k_flat = kh * kw * c_in_ld
+    k_pad = round_up(k_flat, 32)
+    p = torch.zeros((cout_pad, kh * kw, c_in_ld), dtype=torch.float32, device=w.device)
+    p[:cout, :, :cin] = wf.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    out = torch.zeros((cout_pad, k_pad), dtype=torch.float32, device=w.device)
+    out[:, :k_flat] = p.reshape(cout_pad, k_flat)
+    return out.contiguous(), cout_pad, c_in_ld
 
 
 def pad_vec(v: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[torch.Tensor]:
@@ -244,27 +253,32 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
                  e1: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, act: int = ACT_NONE,
                  e2: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                  y2d: Optional[torch.Tensor] = None, y_nchw: Optional[torch.Tensor] = None,
-                 tag: str = "conv", c_in_real: Optional[int] = None):
+                 tag: str = "conv", c_in_real: Optional[int] = None, stride: int = 1, pad: Optional[int] = None):
     """One fused convolution (see bts_conv_desc in include/bts_hip.h).
 
     x2d: [B*h_in*w_in, C>=c_in_ld] NHWC view.  Exactly one of y2d ([B*H*W, c_out] NHWC view) /
-    y_nchw ([B,c_out,H,W] contiguous) receives the result."""
+    y_nchw ([B,c_out,H,W] contiguous) receives the result.  pad defaults to dil*(ksize//2)."""
     xs, xc = _rows2d(x2d, "conv_forward")
     _need(w_packed, "conv_forward")
-    taps, c_out_pad, k_pad = w_packed.shape
-    if taps != ksize * ksize or not w_packed.is_contiguous():
-        raise BtsHipError("conv_forward: packed weight/ksize mismatch")
+    c_out_pad, k_pad = w_packed.shape
     if c_in_ld is None:
         c_in_ld = xc
+    taps = ksize * ksize
+    if k_pad != round_up(taps * c_in_ld, 32) or not w_packed.is_contiguous():
+        raise BtsHipError("conv_forward: packed weight [%d,%d] does not match ksize %d / c_in_ld %d"
+                          % (c_out_pad, k_pad, ksize, c_in_ld))
     if c_in_ld % 4 or c_in_ld > xc or x2d.shape[0] != B * h_in * w_in:
         raise BtsHipError("conv_forward: bad input view (c_in_ld %d, view %s)" % (c_in_ld, tuple(x2d.shape)))
-    H, W = h_in * up, w_in * up
+    if pad is None:
+        pad = dil * (ksize // 2)
+    H = (h_in * up + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
+    W = (w_in * up + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
     d = ConvDesc()
     d.x, d.x_pix_stride, d.c_in_ld, d.k_pad = x2d.data_ptr(), xs, c_in_ld, k_pad
-    d.B, d.h_in, d.w_in, d.up, d.ksize, d.dil = B, h_in, w_in, up, ksize, dil
+    d.B, d.h_in, d.w_in, d.up, d.ksize, d.dil, d.stride, d.pad = B, h_in, w_in, up, ksize, dil, stride, pad
     d.w, d.c_out, d.c_out_pad = w_packed.data_ptr(), c_out, c_out_pad
     keep = []
-    for name, pair, n in (("pre", pre, k_pad), ("e1", e1, c_out_pad), ("e2", e2, c_out_pad)):
+    for name, pair, n in (("pre", pre, c_in_ld), ("e1", e1, c_out_pad), ("e2", e2, c_out_pad)):
         if pair is not None:
             s, b = pair
             if s.numel() != n or b.numel() != n:
@@ -293,8 +307,11 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     npix_out = B * H * W
     flops = 2.0 * npix_out * c_out * cin * taps
     nbytes = 4.0 * (B * h_in * w_in * cin + npix_out * c_out + taps * c_out * cin)
-    variant = "conv_fwd_kernel<128,%d,%s>" % (128 if (c_out_pad >= 128 or c_out_pad == 96) else (64 if c_out_pad == 64 else 32),
-                                             "nchw" if y_nchw is not None else "nhwc")
+    variant = "conv"
+    if _trace is not None:
+        bm, bn = C.c_int(0), C.c_int(0)
+        _lib.load().bts_conv_plan_f32(C.byref(d), C.byref(bm), C.byref(bn))
+        variant = "conv_fwd_kernel<%d,%d,%s>" % (bm.value, bn.value, "nchw" if y_nchw is not None else "nhwc")
     with torch.cuda.device(x2d.device):
         rc = _launch(variant, tag, flops, nbytes, lambda: _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d)))
     _lib.check(rc, "bts_conv_fwd_f32")

@@ -87,23 +87,26 @@ int bts_reduc_fwd_f32(const float* x, long x_pix_stride, long npix, int c_in, in
  *   y[p, n] = E( sum_{tap,c} P(x[q(p,tap), c]) * w[tap][n][c] )
  *   P(v) = pre_relu( v*pre_scale[c] + pre_shift[c] )         (zero padding applied AFTER P)
  *   E(a) = post2( act( a*e1_scale[n] + e1_shift[n] ) ),  post2(v) = v*e2_scale[n] + e2_shift[n]
- *   q(p,tap): input pixel of output pixel p for the tap, with `dil` dilation, padding
- *   dil*(ksize/2) and an optional nearest `up`x upsample of the input folded into the index.
+ *   q(p,tap): input pixel of output pixel p for the tap, with `stride`, `dil`ation, `pad`ding and an
+ *   optional nearest `up`x upsample of the input folded into the index.
  */
 typedef struct bts_conv_desc {
     const float* x;        /* input, NHWC: pixel q channel c at x[q*x_pix_stride + c]              */
     long  x_pix_stride;    /* floats between pixels (>= c_in_ld, multiple of 4)                   */
     int   c_in_ld;         /* loadable input channels (multiple of 4; pad channels must be 0)     */
-    int   k_pad;           /* per-tap K of the packed weights (multiple of 32, >= c_in_ld)        */
+    int   k_pad;           /* padded flattened K of the packed weights: multiple of 32,
+                              >= ksize*ksize*c_in_ld; k = tap*c_in_ld + c                          */
     int   B, h_in, w_in;   /* input spatial size before the optional upsample                     */
     int   up;              /* 1 or 2: nearest upsample folded into the gather (bts.py:91)         */
-    int   ksize;           /* 1 or 3                                                               */
-    int   dil;             /* dilation (= padding) for ksize 3                                     */
-    const float* w;        /* packed weights [ksize*ksize][c_out_pad][k_pad], c_out_pad % 32 == 0  */
+    int   ksize;           /* odd, 1..7                                                            */
+    int   dil;             /* dilation (>= 1)                                                      */
+    int   stride;          /* output stride (1 or 2; must be 1 when up == 2)                       */
+    int   pad;             /* zero padding on each side (reference convs: dil*(ksize/2))           */
+    const float* w;        /* packed weights [c_out_pad][k_pad], c_out_pad % 32 == 0               */
     int   c_out;           /* real output channels                                                 */
     int   c_out_pad;
-    const float* pre_scale;  /* [k_pad] or NULL (identity)                                         */
-    const float* pre_shift;  /* [k_pad] or NULL                                                    */
+    const float* pre_scale;  /* [c_in_ld] or NULL (identity)                                       */
+    const float* pre_shift;  /* [c_in_ld] or NULL                                                  */
     int   pre_relu;
     const float* e1_scale;   /* [c_out_pad] or NULL                                                */
     const float* e1_shift;
@@ -116,6 +119,10 @@ typedef struct bts_conv_desc {
 } bts_conv_desc;
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);
+
+/* Which (BM x BN) output tile bts_conv_fwd_f32 will use for this descriptor (host-side query, no GPU
+ * work): lets a profiler attribute a launch to its kernel instantiation. */
+int bts_conv_plan_f32(const bts_conv_desc* desc, int* bm, int* bn);
 
 /* ------------------------------------------------------------------------------------------
  * Layout movers between the NCHW boundary (pytorch/bts.py:347-349 tensors) and the NHWC

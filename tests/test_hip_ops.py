@@ -187,7 +187,7 @@ def _run_atrous(ops, p, name, x_nchw, dil, first_bn):
     pre = None
     if first_bn:
         s, b = _bn(p, a + ".first_bn", 1.1e-5, ops)
-        pre = (dev(ops.pad_vec(s, k1, 1.0)), dev(ops.pad_vec(b, k1, 0.0)))
+        pre = (dev(ops.pad_vec(s, k1, 1.0)), dev(ops.pad_vec(b, k1, 0.0)))     # k1 == c_in_ld
     s2, b2 = _bn(p, a + ".aconv_sequence.2", 1e-5, ops)
     mid = torch.empty(B * h * w, 256, device="cuda")
     ops.conv_forward(xin, B, h, w, w1, 256, 1, pre=pre, pre_relu=True,
@@ -235,7 +235,7 @@ def test_conv3x3_generic(ops, cin, cout, up, act, nchw):
     cin_ld = ops.round_up(cin, 4)
     xin = torch.zeros(B * h * w, cin_ld, device="cuda")
     ops.nchw_to_nhwc(dev(x), xin[:, :cin])
-    wp, cop, kp = ops.pack_conv_weight(dev(wt))
+    wp, cop, kp = ops.pack_conv_weight(dev(wt), c_in_ld=cin_ld)
     e2 = (dev(ops.pad_vec(torch.from_numpy(sc), cop, 1.0)), dev(ops.pad_vec(torch.from_numpy(sh), cop, 0.0)))
     H, W = h * up, w * up
     if nchw:
@@ -246,6 +246,26 @@ def test_conv3x3_generic(ops, cin, cout, up, act, nchw):
         ops.conv_forward(xin, B, h, w, wp, cout, 3, dil=1, up=up, c_in_ld=cin_ld, act=act, e2=e2, y2d=yb)
         y = ops.nhwc_to_nchw(yb, B, H, W)
     close(y, ref, rtol=1e-4, atol=2e-5, what="conv3x3 %d->%d up%d" % (cin, cout, up))
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,hw", [(3, 96, 7, 2, 3, 1, (38, 52)), (48, 64, 3, 2, 1, 1, (17, 23)),
+                                                          (20, 32, 5, 1, 2, 1, (9, 11)), (64, 128, 1, 2, 0, 1, (10, 12)),
+                                                          (16, 48, 3, 1, 2, 2, (12, 9))])
+def test_conv_stride_pad_general(ops, cin, cout, k, stride, pad, dil, hw):
+    """Encoder-side shapes: the 7x7/2 stem (3 channels padded to 4), strided 3x3 and 1x1, 48-wide outputs."""
+    B, (h, w) = 2, hw
+    rng = np.random.Generator(np.random.PCG64(cin + 13 * cout + k))
+    x = rng.standard_normal(size=(B, cin, h, w), dtype=np.float32)
+    wt = (rng.standard_normal(size=(cout, cin, k, k)) * 0.1).astype(np.float32)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(wt), stride=stride, padding=pad, dilation=dil)
+    cin_ld = ops.round_up(cin, 4)
+    xin = torch.zeros(B * h * w, cin_ld, device="cuda")
+    ops.nchw_to_nhwc(dev(x), xin[:, :cin])
+    wp, cop, cld = ops.pack_conv_weight(dev(wt))
+    H, W = ref.shape[2], ref.shape[3]
+    yb = torch.zeros(B * H * W, cout, device="cuda")
+    ops.conv_forward(xin, B, h, w, wp, cout, k, dil=dil, stride=stride, pad=pad, y2d=yb)
+    close(ops.nhwc_to_nchw(yb, B, H, W), ref, rtol=1e-4, atol=2e-5, what="conv k%d s%d" % (k, stride))
 
 
 def test_conv_k_permutation(ops):

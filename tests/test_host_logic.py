@@ -29,8 +29,8 @@ def test_cabi_exports_every_declared_symbol():
 
 def test_conv_desc_layout_matches_header():
     from bts_amd._lib import ConvDesc
-    assert ctypes.sizeof(ConvDesc) == 152
-    assert ConvDesc.w.offset == 48 and ConvDesc.y.offset == 128 and ConvDesc.y_nchw.offset == 144
+    assert ctypes.sizeof(ConvDesc) == 160
+    assert ConvDesc.w.offset == 56 and ConvDesc.y.offset == 136 and ConvDesc.y_nchw.offset == 152
 
 
 @pytest.mark.parametrize("enc", ["densenet161_bts", "resnext101_bts", "densenet121_bts", "resnet50_bts"])
@@ -92,13 +92,13 @@ def test_hot_path_fails_loudly_without_gpu():
 def test_pack_layouts():
     from bts_amd import ops
     w = torch.arange(2 * 5 * 9, dtype=torch.float32).reshape(2, 5, 3, 3)
-    p, cop, kp = ops.pack_conv_weight(w)
-    assert (cop, kp) == (32, 32) and tuple(p.shape) == (9, 32, 32)
-    assert p[4, 1, 3] == w[1, 3, 1, 1] and p[0, 0, 0] == w[0, 0, 0, 0] and p[8, 1, 4] == w[1, 4, 2, 2]
-    assert p[:, 2:, :].abs().sum() == 0 and p[:, :, 5:].abs().sum() == 0
+    p, cop, cld = ops.pack_conv_weight(w)                  # K flattened tap-major: k = tap*c_in_ld + c
+    assert (cop, cld) == (32, 8) and tuple(p.shape) == (32, 96)      # 9*8 = 72 -> 96
+    assert p[1, 4 * 8 + 3] == w[1, 3, 1, 1] and p[0, 0] == w[0, 0, 0, 0] and p[1, 8 * 8 + 4] == w[1, 4, 2, 2]
+    assert p[2:].abs().sum() == 0 and p[:, 72:].abs().sum() == 0 and p[:, 5:8].abs().sum() == 0
     perm = torch.tensor([4, 0, 1, 2, 3])
     pp, _, _ = ops.pack_conv_weight(w, perm=perm)
-    assert pp[4, 1, 0] == w[1, 4, 1, 1]
+    assert pp[1, 4 * 8 + 0] == w[1, 4, 1, 1]
     # reduction fragments: float4 ((mt*(K/8)+g)*64 + 32h + i) = W[32mt+i][4(2g+h) .. +3]
     w1 = torch.arange(16 * 32, dtype=torch.float32).reshape(16, 32, 1, 1)
     f = ops.pack_reduc_weights([w1]).view(-1, 4)
