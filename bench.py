@@ -112,9 +112,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step all-gather of the 5 depth maps (N>1)")
     ap.add_argument("--decoder-only", action="store_true", help="time only the decoder hot path on encoder-shaped features")
-    ap.add_argument("--miopen", action="store_true",
-                    help="let the torch encoder use MIOpen (this image has no gfx950 find-db: the first pass JIT-compiles "
-                         "~160 conv configs for >7 min); default runs the encoder on ATen's native conv path")
+    ap.add_argument("--encoder-backend", choices=["hip", "aten", "miopen"], default="hip",
+                    help="hip: DenseNet encoder on the HIP conv kernel (default); aten: torch encoder on ATen's native "
+                         "conv path; miopen: torch encoder on MIOpen (no gfx950 find-db in this image: the first pass "
+                         "JIT-compiles ~160 conv configs for >7 min)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,7 +129,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     torch.backends.cudnn.benchmark = False
-    torch.backends.cudnn.enabled = bool(args.miopen)
+    torch.backends.cudnn.enabled = args.encoder_backend == "miopen"
 
     from bts_amd import dist as bdist, ops, synth
     is_kitti = True
@@ -136,6 +137,7 @@ def main():
     B, H, W = args.batch, args.height, args.width
     log("building model %s" % args.encoder)
     model = build_model(params, device, seed=0)
+    model.native_encoder = args.encoder_backend == "hip"
     bdist.broadcast_module(model, src=0)            # RCCL broadcast of ~188 MB, once
     log("model on %s" % device)
 
@@ -227,29 +229,42 @@ def main():
             dom = max((k for k in summ if k.startswith("conv_fwd_kernel")), key=lambda k: summ[k]["ms"])
             d = summ[dom]
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            aspp = d["tags"].get("aspp")
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
                     "launches_per_step": d["launches"] // nrep,
                     "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
-                    "algorithmic_gflop_per_step": round(d["flops"] / nrep / 1e9, 2)}
-            if aspp:
-                a_t = aspp["flops"] / (aspp["ms"] * 1e-3) / 1e12
-                roof["aspp"] = {"launches_per_step": aspp["launches"] // nrep, "ms_per_step": round(aspp["ms"] / nrep, 3),
-                                "gflop_per_step": round(aspp["flops"] / nrep / 1e9, 2), "achieved": round(a_t, 2),
-                                "frac": round(a_t / PEAK_MFMA_F32_TFLOPS, 4)}
-            others = {}
+                    "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
+            # the same accounting per call-site group (tags) over every conv instantiation
+            tags = {}
             for k, v in summ.items():
-                if k == dom:
-                    continue
+                for t, tv in v["tags"].items():
+                    g = tags.setdefault(t, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+                    for f in g:
+                        g[f] += tv[f]
+            groups = {}
+            for t, g in sorted(tags.items()):
+                e = {"launches_per_step": g["launches"] // nrep, "ms_per_step": round(g["ms"] / nrep, 3)}
+                if g["flops"] > 0 and (t.startswith("enc") or t in ("aspp", "decoder_conv")):
+                    tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
+                    e.update(gflop_per_step=round(g["flops"] / nrep / 1e9, 2), achieved_tflops=round(tf, 2),
+                             frac_mfma=round(tf / PEAK_MFMA_F32_TFLOPS, 4))
+                else:
+                    gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+                    e.update(gbs=round(gbs, 1), frac_hbm=round(gbs / PEAK_HBM_GBS, 4))
+                groups[t] = e
+            roof["groups"] = groups
+            kern = {}
+            for k, v in summ.items():
                 e = {"ms_per_step": round(v["ms"] / nrep, 4), "launches_per_step": v["launches"] // nrep}
                 if k.startswith("conv"):
                     e["tflops"] = round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)
                 else:
                     e["gbs"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
-                    e["frac_hbm"] = round(e["gbs"] / PEAK_HBM_GBS, 4)
-                others[k] = e
-            roof["other_kernels"] = others
+                kern[k] = e
+            roof["kernels"] = kern
+            conv_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("conv"))
+            conv_fl = sum(v["flops"] for k, v in summ.items() if k.startswith("conv"))
+            roof["all_conv"] = {"ms_per_step": round(conv_ms / nrep, 3), "achieved_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
             roof["hip_kernels_ms_per_step"] = round(sum(v["ms"] for v in summ.values()) / nrep, 3)
 
     if rank == 0:
@@ -264,7 +279,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "image": "%dx%d" % (H, W),
                        "parallelism": "dp%d batch-sharded, RCCL weight broadcast once%s" % (
                            world, ", all-gather of 5 depth maps per step" if gather else ""),
-                       "hipgraph": graph is not None, "encoder_backend": "miopen" if args.miopen else "aten-native",
+                       "hipgraph": graph is not None, "encoder_backend": args.encoder_backend,
                        "weights": "random-init encoder + PCG64(0) synthetic decoder"},
             "roofline": roof,
         }

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libbts_hip.so")
 SYMBOLS = (
     "bts_hip_abi_version", "bts_hip_error_string", "bts_lpg_fwd_f32", "bts_lpg_fused_fwd_f32",
     "bts_reduc_fwd_f32", "bts_conv_fwd_f32", "bts_nchw_to_nhwc_f32", "bts_nhwc_to_nchw_f32",
-    "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32",
+    "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32", "bts_maxpool3x3s2_nhwc_f32", "bts_bn_relu_avgpool2_nhwc_f32",
 )
 
 ABI_VERSION = 1
@@ -31,6 +31,7 @@ class ConvDesc(C.Structure):
         ("e1_scale", C.c_void_p), ("e1_shift", C.c_void_p), ("act", C.c_int),
         ("e2_scale", C.c_void_p), ("e2_shift", C.c_void_p),
         ("y", C.c_void_p), ("y_pix_stride", C.c_long), ("y_nchw", C.c_int),
+        ("y2", C.c_void_p), ("y2_pix_stride", C.c_long),
     ]
 
 
@@ -73,6 +74,10 @@ def load():
     lib.bts_nchw_to_nhwc_f32.argtypes = [vp, i, i, l, vp, l, i, vp]
     lib.bts_nhwc_to_nchw_f32.restype = i
     lib.bts_nhwc_to_nchw_f32.argtypes = [vp, l, i, i, l, vp, vp]
+    lib.bts_maxpool3x3s2_nhwc_f32.restype = i
+    lib.bts_maxpool3x3s2_nhwc_f32.argtypes = [vp, l, i, i, i, i, vp, l, vp, l, vp]
+    lib.bts_bn_relu_avgpool2_nhwc_f32.restype = i
+    lib.bts_bn_relu_avgpool2_nhwc_f32.argtypes = [vp, l, i, i, i, i, vp, vp, vp, l, vp]
     lib.bts_pack_planes_f32.restype = i
     lib.bts_pack_planes_f32.argtypes = [vp, vp, vp, vp, i, l, vp, l, vp]
     lib.bts_get_depth_f32.restype = i

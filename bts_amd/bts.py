@@ -376,35 +376,49 @@ class bts(nn.Module):
         self._bufs[key] = ws
         return ws
 
+    def skip_slots(self, ws):
+        """The four NHWC channel slices of the decoder's concat buffers that hold the encoder taps
+        (skip0 @H/2, skip1 @H/4, skip2 @H/8, skip3 @H/16): an NHWC producer can write them in place."""
+        nf, f = self.num_features, self.feat_out_channels
+        return [ws["cat2"][:, nf // 8:nf // 8 + f[0]], ws["cat3"][:, nf // 4:nf // 4 + f[1]],
+                ws["x8"][:, nf // 2:nf // 2 + f[2]], ws["cat5"][:, nf:nf + f[3]]]
+
     def forward(self, features, focal):
+        """bts.forward(features, focal), bts.py:223-293: NCHW encoder taps in, the reference's 6-tuple out."""
         _require_eval(self, "bts")
         skip0, skip1, skip2, skip3, dense = features[1], features[2], features[3], features[4], features[5]
         ops._need(dense, "bts.forward")
         B = dense.shape[0]
         H, W = dense.shape[2] * 32, dense.shape[3] * 32
-        dev = dense.device
+        f = self.feat_out_channels
+        ws = self._workspace(B, H, W, dense.device)
+        # boundary: NCHW encoder taps -> NHWC channel slices (dense_features = ReLU(features[5]), bts.py:225)
+        ops.nchw_to_nhwc(dense, ws["f5"][:, :f[4]], relu=True)
+        for src, dst in zip((skip0, skip1, skip2, skip3), self.skip_slots(ws)):
+            ops.nchw_to_nhwc(src, dst)
+        return self.forward_nhwc(ws, B, H, W, focal, ws["f5"], None, False)
+
+    def forward_nhwc(self, ws, B, H, W, focal, dense2d, dense_pre, dense_relu):
+        """The decoder proper on NHWC buffers.  ``ws``: this module's workspace with the four skip slots
+        already filled; ``dense2d``: the 1/32-resolution features [npix, C>=f[4]] and the prologue
+        (affine, relu) still to be applied to them (norm5 + ReLU when the encoder is fused in)."""
+        _require_eval(self, "bts")
+        dev = dense2d.device
         nf, f = self.num_features, self.feat_out_channels
         md = float(self.params.max_depth)
         P = self.packed()
-        ws = self._workspace(B, H, W, dev)
         h16, w16, h8, w8, h4, w4, h2, w2 = H // 16, W // 16, H // 8, W // 8, H // 4, W // 4, H // 2, W // 2
         ELU = ops.ACT_ELU
 
-        def conv(name_w, x2d, hh, ww, cout, y2d=None, y_nchw=None, up=1, e2=None, c_in_real=None):
+        def conv(name_w, x2d, hh, ww, cout, y2d=None, y_nchw=None, up=1, e2=None, c_in_real=None, pre=None,
+                 pre_relu=False):
             wp = P[name_w] if isinstance(name_w, str) else name_w
-            return ops.conv_forward(x2d, B, hh, ww, wp[0], cout, 3, dil=1, up=up, act=ELU, e2=e2,
+            return ops.conv_forward(x2d, B, hh, ww, wp[0], cout, 3, dil=1, up=up, act=ELU, e2=e2, pre=pre, pre_relu=pre_relu,
                                     y2d=y2d, y_nchw=y_nchw, tag="decoder_conv", c_in_real=c_in_real)
 
-        # boundary: NCHW encoder taps -> NHWC channel slices (dense_features = ReLU(features[5]), bts.py:225)
-        ops.nchw_to_nhwc(dense, ws["f5"][:, :f[4]], relu=True)
-        ops.nchw_to_nhwc(skip3, ws["cat5"][:, nf:nf + f[3]])
-        ops.nchw_to_nhwc(skip2, ws["x8"][:, nf // 2:nf // 2 + f[2]])
-        ops.nchw_to_nhwc(skip1, ws["cat3"][:, nf // 4:nf // 4 + f[1]])
-        ops.nchw_to_nhwc(skip0, ws["cat2"][:, nf // 8:nf // 8 + f[0]])
-
         # H/16 and H/8 trunk (bts.py:226-235)
-        conv(self.upconv5.packed(), ws["f5"], H // 32, W // 32, nf, y2d=ws["cat5"][:, :nf], up=2, e2=P["bn5"],
-             c_in_real=f[4])
+        conv(self.upconv5.packed(), dense2d, H // 32, W // 32, nf, y2d=ws["cat5"][:, :nf], up=2, e2=P["bn5"],
+             c_in_real=f[4], pre=dense_pre, pre_relu=dense_relu)
         conv("conv5", ws["cat5"], h16, w16, nf, y2d=ws["iconv5"], c_in_real=nf + f[3])
         x8 = ws["x8"]
         c_cat4 = nf // 2 + f[2]
@@ -501,13 +515,30 @@ class encoder(nn.Module):
 
 
 class BtsModel(nn.Module):
-    """bts.py:341-349."""
+    """bts.py:341-349.  Same constructor and forward signature.
+
+    With a DenseNet encoder, eval mode and a GPU input the whole forward is native: the encoder runs on
+    the HIP conv kernel (bts_amd.encoder_hip) writing its taps straight into the decoder's NHWC concat
+    buffers.  Other encoders (ResNet/ResNeXt) run on PyTorch-ROCm as in the reference and hand NCHW taps
+    to the HIP decoder."""
 
     def __init__(self, params):
         super(BtsModel, self).__init__()
         self.encoder = encoder(params)
         self.decoder = bts(params, self.encoder.feat_out_channels, params.bts_size)
+        self.native_encoder = True          # set False to force the torch encoder (A/B, debugging)
+        self._enc_hip = None
 
     def forward(self, x, focal):
+        if (self.native_encoder and 'densenet' in self.encoder.params.encoder and not self.training
+                and isinstance(x, torch.Tensor) and x.is_cuda):
+            from .encoder_hip import DenseNetHip
+            if self._enc_hip is None or self._enc_hip.features is not self.encoder.base_model:
+                self._enc_hip = DenseNetHip(self.encoder.base_model)
+            B, _, H, W = x.shape
+            dec = self.decoder
+            ws = dec._workspace(B, H, W, x.device)
+            r = self._enc_hip.run(x.float(), dec.skip_slots(ws))
+            return dec.forward_nhwc(ws, B, H, W, focal, r["dense"], r["norm5"], True)
         skip_feat = self.encoder(x)
         return self.decoder(skip_feat, focal)

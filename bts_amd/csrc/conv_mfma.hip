@@ -42,6 +42,7 @@ struct ConvArgs {
     const float* e1_scale; const float* e1_shift; int act;
     const float* e2_scale; const float* e2_shift;
     float* y; long y_pix_stride;
+    float* y2; long y2_pix_stride;   // optional second NHWC destination
     int H, W;                        // output spatial size
     int Hs, Ws;                      // (upsampled) source extent the taps index: h_in*up, w_in*up
     long M;                          // B*H*W
@@ -235,7 +236,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
                     if (has_e1) v = v * s1 + b1;
                     v = apply_act(v, a.act);
                     if (has_e2) v = v * s2 + b2;
-                    if (nok && m < a.M) a.y[m * a.y_pix_stride + n] = v;
+                    if (nok && m < a.M) {
+                        a.y[m * a.y_pix_stride + n] = v;
+                        if (a.y2) a.y2[m * a.y2_pix_stride + n] = v;
+                    }
                 }
             } else {
                 const long m = m0 + (wm * TM + i) * 32 + li;
@@ -288,17 +292,25 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s) {
 // finishes ceil(n_wg / 256 CUs) "tile rounds", so 836 tiles of 128 rows cost 4 rounds (82 % busy)
 // while 1672 tiles of 64 rows cost 7 half-rounds (93 %).  The 64-row tile pays ~5 % more staging.
 void choose_tile(long M, int c_out_pad, int* bm, int* bn) {
-    *bn = (c_out_pad >= 128 || c_out_pad == 96) ? 128 : (c_out_pad == 64 ? 64 : 32);
+    // BN: least padded width, weighted by how well each tile shape runs (128: 1.0, 64: 1.05, 32: 1.2)
+    const int cand[3] = {128, 64, 32};
+    const double eff[3] = {1.0, 1.05, 1.2};
+    double best = 1e30;
+    for (int i = 0; i < 3; ++i) {
+        const double cost = (double)((c_out_pad + cand[i] - 1) / cand[i] * cand[i]) * eff[i];
+        if (cost < best) { best = cost; *bn = cand[i]; }
+    }
     *bm = 128;
-    if (*bn == 32) return;
-    const long nt = (c_out_pad + *bn - 1) / *bn;
-    const long wg128 = ((M + 127) / 128) * nt, wg64 = ((M + 63) / 64) * nt;
-    const double t128 = (double)((wg128 + 255) / 256) * 128.0;
-    const double t64 = (double)((wg64 + 255) / 256) * 64.0 * 1.05;
-    if (t64 < t128) *bm = 64;
+    if (*bn != 32) {
+        const long nt = (c_out_pad + *bn - 1) / *bn;
+        const long wg128 = ((M + 127) / 128) * nt, wg64 = ((M + 63) / 64) * nt;
+        const double t128 = (double)((wg128 + 255) / 256) * 128.0;
+        const double t64 = (double)((wg64 + 255) / 256) * 64.0 * 1.05;
+        if (t64 < t128) *bm = 64;
+    }
     if (const char* f = getenv("BTS_CONV_BM")) {       // tuning aid: force the row tile (64 / 128)
         const int v = atoi(f);
-        if (v == 64 || v == 128) *bm = v;
+        if ((v == 64 && *bn != 32) || v == 128) *bm = v;
     }
 }
 
@@ -338,6 +350,8 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     a.e1_scale = d->e1_scale; a.e1_shift = d->e1_shift; a.act = d->act;
     a.e2_scale = d->e2_scale; a.e2_shift = d->e2_shift;
     a.y = d->y; a.y_pix_stride = d->y_pix_stride;
+    a.y2 = d->y2; a.y2_pix_stride = d->y2_pix_stride;
+    if (d->y2 && (d->y_nchw || d->y2_pix_stride < d->c_out)) return BTS_ERR_INVALID;
     a.Hs = d->h_in * d->up; a.Ws = d->w_in * d->up;
     a.H = (a.Hs + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
     a.W = (a.Ws + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;

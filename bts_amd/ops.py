@@ -253,7 +253,8 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
                  e1: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, act: int = ACT_NONE,
                  e2: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                  y2d: Optional[torch.Tensor] = None, y_nchw: Optional[torch.Tensor] = None,
-                 tag: str = "conv", c_in_real: Optional[int] = None, stride: int = 1, pad: Optional[int] = None):
+                 tag: str = "conv", c_in_real: Optional[int] = None, stride: int = 1, pad: Optional[int] = None,
+                 y2_2d: Optional[torch.Tensor] = None):
     """One fused convolution (see bts_conv_desc in include/bts_hip.h).
 
     x2d: [B*h_in*w_in, C>=c_in_ld] NHWC view.  Exactly one of y2d ([B*H*W, c_out] NHWC view) /
@@ -297,6 +298,11 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
             raise BtsHipError("conv_forward: bad output view")
         d.y, d.y_pix_stride, d.y_nchw = y2d.data_ptr(), ys, 0
         out = y2d
+        if y2_2d is not None:
+            y2s, y2c = _rows2d(y2_2d, "conv_forward")
+            if y2c != c_out or y2_2d.shape[0] != B * H * W:
+                raise BtsHipError("conv_forward: bad second output view")
+            d.y2, d.y2_pix_stride = y2_2d.data_ptr(), y2s
     else:
         _need(y_nchw, "conv_forward")
         if tuple(y_nchw.shape) != (B, c_out, H, W) or not y_nchw.is_contiguous():
@@ -355,3 +361,42 @@ def get_depth_forward(iconv1: torch.Tensor, weight: torch.Tensor, max_depth: flo
                                            _ptr(out), _stream(iconv1))
     _lib.check(rc, "bts_get_depth_f32")
     return out
+
+
+# --------------------------------------------------------------------------- pooling
+def maxpool3x3s2(src2d: torch.Tensor, B: int, h: int, w: int, dst2d: torch.Tensor, dst2_2d: Optional[torch.Tensor] = None):
+    ss, Cc = _rows2d(src2d, "maxpool3x3s2")
+    ds, dc = _rows2d(dst2d, "maxpool3x3s2")
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    if dc != Cc or src2d.shape[0] != B * h * w or dst2d.shape[0] != B * ho * wo:
+        raise BtsHipError("maxpool3x3s2: shape mismatch")
+    d2p, d2s = C.c_void_p(0), 0
+    if dst2_2d is not None:
+        d2s, d2c = _rows2d(dst2_2d, "maxpool3x3s2")
+        if d2c != Cc or dst2_2d.shape[0] != B * ho * wo:
+            raise BtsHipError("maxpool3x3s2: second destination mismatch")
+        d2p = _ptr(dst2_2d)
+    nbytes = 4.0 * Cc * (B * h * w + B * ho * wo * (2 if dst2_2d is not None else 1))
+    with torch.cuda.device(src2d.device):
+        rc = _launch("maxpool3x3s2_kernel", "encoder_pool", 0.0, nbytes,
+                     lambda: _lib.load().bts_maxpool3x3s2_nhwc_f32(_ptr(src2d), ss, B, h, w, Cc, _ptr(dst2d), ds, d2p, d2s,
+                                                                   _stream(src2d)))
+    _lib.check(rc, "bts_maxpool3x3s2_nhwc_f32")
+    return dst2d
+
+
+def bn_relu_avgpool2(src2d: torch.Tensor, B: int, h: int, w: int, scale: torch.Tensor, shift: torch.Tensor,
+                     dst2d: torch.Tensor):
+    ss, Cc = _rows2d(src2d, "bn_relu_avgpool2")
+    ds, dc = _rows2d(dst2d, "bn_relu_avgpool2")
+    _need(scale, "bn_relu_avgpool2")
+    _need(shift, "bn_relu_avgpool2")
+    if dc != Cc or src2d.shape[0] != B * h * w or dst2d.shape[0] != B * (h // 2) * (w // 2) or scale.numel() != Cc:
+        raise BtsHipError("bn_relu_avgpool2: shape mismatch")
+    nbytes = 4.0 * Cc * (B * h * w + B * (h // 2) * (w // 2))
+    with torch.cuda.device(src2d.device):
+        rc = _launch("bn_relu_avgpool2_kernel", "encoder_pool", 0.0, nbytes,
+                     lambda: _lib.load().bts_bn_relu_avgpool2_nhwc_f32(_ptr(src2d), ss, B, h, w, Cc, _ptr(scale), _ptr(shift),
+                                                                       _ptr(dst2d), ds, _stream(src2d)))
+    _lib.check(rc, "bts_bn_relu_avgpool2_nhwc_f32")
+    return dst2d

@@ -116,6 +116,9 @@ typedef struct bts_conv_desc {
     float* y;                /* output                                                             */
     long  y_pix_stride;      /* NHWC: floats between pixels; ignored for NCHW                      */
     int   y_nchw;            /* 0: y[p*y_pix_stride + n]; 1: y[(b*c_out + n)*H*W + yx] (boundary)  */
+    float* y2;               /* optional second NHWC destination of the same result (a skip tensor
+                                that must live in two concat buffers), or NULL                      */
+    long  y2_pix_stride;
 } bts_conv_desc;
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);
@@ -141,6 +144,18 @@ int bts_nhwc_to_nchw_f32(const float* src, long src_pix_stride, int B, int C, lo
  */
 int bts_pack_planes_f32(const float* p0, const float* p1, const float* p2, const float* p3, int n_planes,
                         long npix, float* dst, long dst_pix_stride, bts_stream_t stream);
+
+/* Encoder-side NHWC pooling (torchvision DenseNet pool0 = MaxPool2d(3,2,1), transition pool =
+ * AvgPool2d(2,2); the encoder is the caller side of the hot path, pytorch/bts.py:295-338).
+ * maxpool: [B,h,w,C] -> [B,ceil(h/2),ceil(w/2),C], optionally to two destinations.
+ * bn_relu_avgpool2: dst = mean_{2x2} relu(src*scale + shift)  (transition norm+relu+pool; its 1x1 conv
+ * commutes with the mean and runs afterwards on the pooled map).  C % 4 == 0, strides % 4 == 0.
+ */
+int bts_maxpool3x3s2_nhwc_f32(const float* src, long src_pix_stride, int B, int h, int w, int C, float* dst,
+                              long dst_pix_stride, float* dst2, long dst2_pix_stride, bts_stream_t stream);
+int bts_bn_relu_avgpool2_nhwc_f32(const float* src, long src_pix_stride, int B, int h, int w, int C,
+                                  const float* scale, const float* shift, float* dst, long dst_pix_stride,
+                                  bts_stream_t stream);
 
 /* get_depth + final scaling (pytorch/bts.py:220-221, 289-291):
  *   final_depth[b,0,y,x] = max_depth * sigmoid( conv3x3(iconv1, w)[b,0,y,x] ) [* focal[b] / 715.0873]

@@ -1,0 +1,102 @@
+"""GPU: the DenseNet encoder on the HIP conv kernel (bts_amd.encoder_hip) against the same nn modules
+run by PyTorch on the CPU, and the fused BtsModel.forward against CPU encoder + oracle decoder."""
+import numpy as np
+import pytest
+import torch
+
+from bts_amd import synth
+from oracle import bts_oracle as O
+from parity_util import Params, check_outputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomise_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = torch.empty_like(m.weight).uniform_(0.8, 1.2, generator=g)
+            m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.05
+            m.running_mean = torch.randn(m.running_mean.shape, generator=g) * 0.05
+            m.running_var = torch.empty_like(m.running_var).uniform_(0.8, 1.2, generator=g)
+
+
+@pytest.mark.parametrize("enc,shape", [("densenet161_bts", (2, 64, 96)), ("densenet121_bts", (1, 96, 64))])
+def test_densenet_hip_taps_vs_torch_cpu(enc, shape):
+    from bts_amd import bts as M
+    from bts_amd.encoder_hip import DenseNetHip
+    torch.manual_seed(3)
+    e = M.encoder(Params(enc, 512, 80.0, "kitti")).eval()
+    _randomise_bn(e, 5)
+    B, H, W = shape
+    x = torch.from_numpy(synth.image_batch(B, H, W, 21))
+    with torch.no_grad():
+        ref = e(x)
+    eg = M.encoder(Params(enc, 512, 80.0, "kitti")).eval()
+    eg.load_state_dict(e.state_dict())
+    eg = eg.cuda()
+    plan = DenseNetHip(eg.base_model)
+    with torch.no_grad():
+        got = plan.taps_nchw(x.cuda())
+    assert len(got) == len(ref) == 6
+    for i in range(1, 6):
+        r, g = ref[i], got[i].cpu()
+        assert r.shape == g.shape
+        scale = r.abs().max().item()
+        err = (r - g).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-5, "tap %d: max abs err %g (scale %g)" % (i, err, scale)
+
+
+def test_btsmodel_fused_forward_vs_cpu():
+    """BtsModel.forward (HIP encoder + HIP decoder, taps written in place) == CPU torch encoder + oracle decoder."""
+    from bts_amd import bts as M
+    params = Params("densenet161_bts", 512, 80.0, "kitti")
+    torch.manual_seed(11)
+    model = M.BtsModel(params).eval()
+    _randomise_bn(model.encoder, 7)
+    feat = synth.ENCODER_CHANNELS[params.encoder]
+    state_np = synth.decoder_state(feat, 512, 0)
+    model.decoder.load_state_dict({k: (torch.tensor(v) if np.ndim(v) == 0 else torch.from_numpy(v.copy())) for k, v in state_np.items()})
+    B, H, W = 2, 64, 96
+    x = torch.from_numpy(synth.image_batch(B, H, W, 5))
+    focal = torch.from_numpy(synth.focal_values(B, "kitti", 5))
+    with torch.no_grad():
+        feats = model.encoder(x)
+        ref_outs, inter = O.decoder_forward(O.state_from_numpy(state_np), feats, focal, 80.0, "kitti", want_intermediates=True)
+    mg = M.BtsModel(params).eval()
+    mg.load_state_dict(model.state_dict())
+    mg = mg.cuda()
+    with torch.no_grad():
+        got = mg(x.cuda(), focal.cuda())
+        mg.native_encoder = False                      # torch encoder (NCHW taps) + HIP decoder: same answer
+        got2 = mg(x.cuda(), focal.cuda())
+    rep = check_outputs(got, ref_outs, inter, rel_tol=5e-4, what="fused BtsModel")
+    print("fused model max-rel:", rep)
+    check_outputs(got2, ref_outs, inter, rel_tol=5e-4, what="torch-encoder BtsModel")
+
+
+def test_pooling_kernels():
+    from bts_amd import ops
+    import torch.nn.functional as F
+    rng = np.random.Generator(np.random.PCG64(8))
+    B, C, h, w = 2, 24, 9, 14
+    x = torch.from_numpy(rng.standard_normal(size=(B, C, h, w), dtype=np.float32))
+    src = torch.zeros(B * h * w, C + 8, device="cuda")
+    ops.nchw_to_nhwc(x.cuda(), src[:, 4:4 + C])
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    d1 = torch.zeros(B * ho * wo, C, device="cuda")
+    d2 = torch.zeros(B * ho * wo, C + 4, device="cuda")
+    ops.maxpool3x3s2(src[:, 4:4 + C], B, h, w, d1, d2[:, 4:])
+    ref = F.max_pool2d(x, 3, 2, 1)
+    assert torch.equal(ops.nhwc_to_nchw(d1, B, ho, wo).cpu(), ref)
+    assert torch.equal(ops.nhwc_to_nchw(d2[:, 4:], B, ho, wo).cpu(), ref)
+    h, w = 8, 14
+    x = torch.from_numpy(rng.standard_normal(size=(B, C, h, w), dtype=np.float32))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, size=C).astype(np.float32))
+    sh = torch.from_numpy(rng.standard_normal(size=C).astype(np.float32) * 0.3)
+    src = torch.zeros(B * h * w, C, device="cuda")
+    ops.nchw_to_nhwc(x.cuda(), src)
+    dst = torch.zeros(B * (h // 2) * (w // 2), C, device="cuda")
+    ops.bn_relu_avgpool2(src, B, h, w, sc.cuda(), sh.cuda(), dst)
+    ref = F.avg_pool2d(F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 2, 2)
+    torch.testing.assert_close(ops.nhwc_to_nchw(dst, B, h // 2, w // 2).cpu(), ref, rtol=1e-5, atol=1e-6)

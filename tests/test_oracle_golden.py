@@ -121,3 +121,25 @@ def test_decoder_full_samples(golden_dir, states, cname):
         st = g["%s_%s_stats" % (cname, n)]
         fin = flat[np.isfinite(flat)]
         assert fin.min() == st[0] and fin.max() == st[1]
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_c_oracle_lpg_tables(golden_dir, k):
+    """oracle/lpg_oracle.c (built by __graft_entry__.build()) against the same reference-generated tables."""
+    import ctypes
+    so = os.path.join(os.path.dirname(golden_dir), "..", "oracle", "_build", "liblpg_oracle.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(golden_dir), "..", "oracle")])
+    lib = ctypes.CDLL(os.path.abspath(so))
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.lpg_oracle_fwd.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp]
+    g = np.load(os.path.join(golden_dir, "lpg_tables.npz"))
+    for name in ("hand", "orient", "rand"):
+        x = np.ascontiguousarray(g["%s_%d_in" % (name, k)])
+        B, _, h, w = x.shape
+        out = np.empty((B, h * k, w * k), dtype=np.float32)
+        am = np.zeros(1, dtype=np.float32)
+        lib.lpg_oracle_fwd(x.ctypes.data_as(fp), B, h, w, k, out.ctypes.data_as(fp), am.ctypes.data_as(fp))
+        _eq(out, g["%s_%d_out" % (name, k)])
+        assert am[0] == g["%s_%d_absmin" % (name, k)]
