@@ -244,7 +244,7 @@ def main():
             groups = {}
             for t, g in sorted(tags.items()):
                 e = {"launches_per_step": g["launches"] // nrep, "ms_per_step": round(g["ms"] / nrep, 3)}
-                if g["flops"] > 0 and (t.startswith("enc") or t in ("aspp", "decoder_conv")):
+                if g["flops"] > 0 and (t.startswith("enc") or t in ("aspp", "decoder_conv", "decoder_upconv")):
                     tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
                     e.update(gflop_per_step=round(g["flops"] / nrep / 1e9, 2), achieved_tflops=round(tf, 2),
                              frac_mfma=round(tf / PEAK_MFMA_F32_TFLOPS, 4))

@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("e1_scale", C.c_void_p), ("e1_shift", C.c_void_p), ("act", C.c_int),
         ("e2_scale", C.c_void_p), ("e2_shift", C.c_void_p),
         ("y", C.c_void_p), ("y_pix_stride", C.c_long), ("y_nchw", C.c_int),
-        ("y2", C.c_void_p), ("y2_pix_stride", C.c_long),
+        ("subpixel", C.c_int), ("y2", C.c_void_p), ("y2_pix_stride", C.c_long),
     ]
 
 

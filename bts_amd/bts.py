@@ -172,9 +172,13 @@ class upconv(nn.Module):
         self._pack_key = None
 
     def packed(self):
+        """Sub-pixel packing (four 2x2 kernels, ops.pack_upconv_subpixel) for ratio 2, plain 3x3 otherwise."""
         key = _param_key(self)
         if self._pack is None or self._pack_key != key:
-            self._pack = ops.pack_conv_weight(self.conv.weight.detach())
+            if self.ratio == 2:
+                self._pack = ops.pack_upconv_subpixel(self.conv.weight.detach())
+            else:
+                self._pack = ops.pack_conv_weight(self.conv.weight.detach())
             self._pack_key = key
         return self._pack
 
@@ -184,9 +188,10 @@ class upconv(nn.Module):
         xin, B, C, h, w = _nhwc_in(x)
         wp, cop, kp = self.packed()
         cout = self.conv.out_channels
-        y = torch.empty((B, cout, h * self.ratio, w * self.ratio), dtype=torch.float32, device=x.device)
-        ops.conv_forward(xin, B, h, w, wp, cout, 3, dil=1, up=self.ratio, act=ops.ACT_ELU, y_nchw=y)
-        return y
+        r = self.ratio
+        y2d = torch.empty((B * h * r * w * r, cout), dtype=torch.float32, device=x.device)
+        ops.conv_forward(xin, B, h, w, wp, cout, 3, dil=1, up=r, act=ops.ACT_ELU, y2d=y2d, subpixel=(r == 2))
+        return ops.nhwc_to_nchw(y2d, B, h * r, w * r)
 
 
 class reduction_1x1(nn.Sequential):
@@ -414,7 +419,8 @@ class bts(nn.Module):
                  pre_relu=False):
             wp = P[name_w] if isinstance(name_w, str) else name_w
             return ops.conv_forward(x2d, B, hh, ww, wp[0], cout, 3, dil=1, up=up, act=ELU, e2=e2, pre=pre, pre_relu=pre_relu,
-                                    y2d=y2d, y_nchw=y_nchw, tag="decoder_conv", c_in_real=c_in_real)
+                                    y2d=y2d, y_nchw=y_nchw, tag="decoder_upconv" if up == 2 else "decoder_conv",
+                                    c_in_real=c_in_real, subpixel=(up == 2))
 
         # H/16 and H/8 trunk (bts.py:226-235)
         conv(self.upconv5.packed(), dense2d, H // 32, W // 32, nf, y2d=ws["cat5"][:, :nf], up=2, e2=P["bn5"],

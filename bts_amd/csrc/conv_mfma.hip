@@ -28,6 +28,9 @@
 
 namespace {
 
+#ifndef CONV_STAGE_AT
+#define CONV_STAGE_AT 1
+#endif
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
 
@@ -35,6 +38,7 @@ struct ConvArgs {
     const float* x; long x_pix_stride; int c_in_ld; int k_pad;   // k_pad: padded flattened K (taps*c_in_ld rounded to 32)
     int B, h_in, w_in, ups;          // ups = log2(up)
     int ksize, dil, stride, pad;
+    int subpix;                      // 1: sub-pixel upconv (4 parity classes of 2x2 kernels, output scattered x2)
     int k_flat;                      // ksize*ksize*c_in_ld
     unsigned magic_c, magic_ks;      // floor(2^32/d)+1 for d = c_in_ld, ksize: exact n/d for n,d < 2^16
     const float* w; int c_out, c_out_pad;
@@ -47,6 +51,7 @@ struct ConvArgs {
     int Hs, Ws;                      // (upsampled) source extent the taps index: h_in*up, w_in*up
     long M;                          // B*H*W
     int n_ntiles;
+    int tiles_per_class;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -61,7 +66,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // "was this row real" bit goes to `okmask`; nothing consumes the data until stage_to_lds(), which
 // runs after the MFMA block, so the loads' latency hides under the previous step's MFMAs.
 template <int PA, int PB>
-__device__ __forceinline__ void issue_loads(const ConvArgs& a, int it, int lk, const int (&ay)[PA],
+__device__ __forceinline__ void issue_loads(const ConvArgs& a, const float* __restrict__ wbase, int pad_y, int pad_x,
+                                            int it, int lk, const int (&ay)[PA],
                                             const int (&ax)[PA], const unsigned (&abase)[PA], unsigned avalid,
                                             const unsigned (&wrow)[PB], f32x4 (&ra)[PA], f32x4 (&rb)[PB],
                                             f32x4& ps, f32x4& pb, unsigned& okmask) {
@@ -75,7 +81,7 @@ __device__ __forceinline__ void issue_loads(const ConvArgs& a, int it, int lk, c
     const int c = (int)(kk - tap * (unsigned)a.c_in_ld);
     const int ky = (int)__umulhi(tap, a.magic_ks);
     const int kx = (int)tap - ky * a.ksize;
-    const int dy = ky * a.dil - a.pad, dx = kx * a.dil - a.pad;
+    const int dy = ky * a.dil - pad_y, dx = kx * a.dil - pad_x;
     if (a.pre_scale != nullptr) {
         ps = *reinterpret_cast<const f32x4*>(a.pre_scale + c);
         pb = *reinterpret_cast<const f32x4*>(a.pre_shift + c);
@@ -93,7 +99,7 @@ __device__ __forceinline__ void issue_loads(const ConvArgs& a, int it, int lk, c
     okmask = m;
     const unsigned wofs = (unsigned)(it * BK);
 #pragma unroll
-    for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(a.w + (wofs + wrow[p]));
+    for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(wbase + (wofs + wrow[p]));
 }
 
 // Prologue (BN affine + ReLU, reference bts.py:70,72) and zero padding, applied on the way to LDS.
@@ -124,6 +130,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     constexpr int RPP = NT / 8;               // tile rows staged per pass (8 lanes x 16 B per row)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int STAGE_AT = CONV_STAGE_AT;   // g-step after which the next tile is written to LDS (0..3)
     static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "tile/wave layout");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
@@ -135,9 +142,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    const int mt_idx = swz / a.n_ntiles, nt_idx = swz % a.n_ntiles;
+    // sub-pixel upconv: the grid covers 4 parity classes (py,px) of output pixels, each its own GEMM over the
+    // SOURCE pixels with a 2x2 kernel (weights pre-summed per class) -- see bts_conv_desc.subpixel
+    const int cls = swz / a.tiles_per_class;
+    const int tcl = swz - cls * a.tiles_per_class;
+    const int mt_idx = tcl / a.n_ntiles, nt_idx = tcl % a.n_ntiles;
     const long m0 = (long)mt_idx * BM;
     const int n0 = nt_idx * BN;
+    const int spy = cls >> 1, spx = cls & 1;
+    const int pad_y = a.subpix ? 1 - spy : a.pad, pad_x = a.subpix ? 1 - spx : a.pad;
+    const float* __restrict__ wbase = a.w + (size_t)cls * a.c_out_pad * a.k_pad;
 
     const int tid = threadIdx.x;
     const int lrow = tid >> 3, lk = (tid & 7) * 4;
@@ -184,14 +198,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    issue_loads<PA, PB>(a, 0, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
+    issue_loads<PA, PB>(a, wbase, pad_y, pad_x, 0, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
     stage_to_lds<BM, RPP, PA, PB>(a, smem, lrow, lk, ra, rb, ps, pb, okmask);
     __syncthreads();
 
     for (int it = 0; it < nit; ++it) {
         const int buf = it & 1;
         const bool more = it + 1 < nit;
-        if (more) issue_loads<PA, PB>(a, it + 1, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
+        if (more) issue_loads<PA, PB>(a, wbase, pad_y, pad_x, it + 1, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
 
         const float* As = smem + buf * BUF_FLOATS + (wm * TM * 32 + li) * LDS_LD + 4 * lh;
         const float* Bs = smem + buf * BUF_FLOATS + BM * LDS_LD + (wn * TN * 32 + li) * LDS_LD + 4 * lh;
@@ -212,8 +226,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
                         if (NCHW_OUT) acc[i][j] = mfma32x2(fb[j][q], fa[i][q], acc[i][j]);   // rows = channels, lanes = pixels
                         else          acc[i][j] = mfma32x2(fa[i][q], fb[j][q], acc[i][j]);   // rows = pixels, lanes = channels
                     }
+            // The next tile's registers go to the OTHER LDS buffer half-way through this tile's MFMAs: by now
+            // its loads (issued before g = 0) have landed, and the waits / prologue VALU / ds_writes can issue
+            // in the shadow of the remaining MFMAs instead of after them.
+            if (g == STAGE_AT && more)
+                stage_to_lds<BM, RPP, PA, PB>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
         }
-        if (more) stage_to_lds<BM, RPP, PA, PB>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
         __syncthreads();
     }
 
@@ -237,8 +255,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
                     v = apply_act(v, a.act);
                     if (has_e2) v = v * s2 + b2;
                     if (nok && m < a.M) {
-                        a.y[m * a.y_pix_stride + n] = v;
-                        if (a.y2) a.y2[m * a.y2_pix_stride + n] = v;
+                        long op = m;
+                        if (a.subpix) {            // source pixel (b,Y,X) -> output pixel (b, 2Y+py, 2X+px)
+                            const int b = (int)(m / HW), yx = (int)(m % HW);
+                            const int Y = yx / a.W, X = yx - Y * a.W;
+                            op = ((long)b * (2 * a.H) + 2 * Y + spy) * (2 * a.W) + 2 * X + spx;
+                        }
+                        a.y[op * a.y_pix_stride + n] = v;
+                        if (a.y2) a.y2[op * a.y2_pix_stride + n] = v;
                     }
                 }
             } else {
@@ -266,7 +290,8 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s) {
     ConvArgs a = a0;
     const long n_mtiles = (a.M + BM - 1) / BM;
     a.n_ntiles = (a.c_out_pad + BN - 1) / BN;
-    const long nwg = n_mtiles * a.n_ntiles;
+    a.tiles_per_class = (int)(n_mtiles * a.n_ntiles);
+    const long nwg = n_mtiles * a.n_ntiles * (a.subpix ? 4 : 1);
     if (nwg > 0x7fffffffL) return BTS_ERR_INVALID;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     hipError_t e;
@@ -320,7 +345,9 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if (!d || !d->x || !d->w || !d->y) return BTS_ERR_INVALID;
     if (d->B <= 0 || d->h_in <= 0 || d->w_in <= 0 || d->c_out <= 0) return BTS_ERR_INVALID;
     if (d->up != 1 && d->up != 2) return BTS_ERR_UNSUPPORTED;
-    if (d->ksize < 1 || d->ksize > 7 || !(d->ksize & 1)) return BTS_ERR_UNSUPPORTED;
+    if (d->subpixel) {   // 3x3 conv on a nearest-2x upsampled input, as four 2x2 convs on the source
+        if (d->ksize != 2 || d->up != 1 || d->stride != 1 || d->dil != 1 || d->y_nchw) return BTS_ERR_INVALID;
+    } else if (d->ksize < 1 || d->ksize > 7 || !(d->ksize & 1)) return BTS_ERR_UNSUPPORTED;
     if (d->dil < 1 || d->stride < 1 || d->pad < 0) return BTS_ERR_INVALID;
     if (d->up == 2 && d->stride != 1) return BTS_ERR_UNSUPPORTED;
     if (d->c_in_ld <= 0 || (d->c_in_ld & 3) || (d->k_pad % BK) || d->k_pad < d->ksize * d->ksize * d->c_in_ld)
@@ -336,12 +363,12 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if (d->act < 0 || d->act > 3) return BTS_ERR_INVALID;
     // the kernel addresses both operands with 32-bit element offsets
     if ((double)d->B * d->h_in * d->w_in * (double)d->x_pix_stride >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
-    if ((double)d->c_out_pad * (double)d->k_pad >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
+    if ((double)d->c_out_pad * (double)d->k_pad * (d->subpixel ? 4.0 : 1.0) >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
 
     ConvArgs a;
     a.x = d->x; a.x_pix_stride = d->x_pix_stride; a.c_in_ld = d->c_in_ld; a.k_pad = d->k_pad;
     a.B = d->B; a.h_in = d->h_in; a.w_in = d->w_in; a.ups = d->up == 2 ? 1 : 0;
-    a.ksize = d->ksize; a.dil = d->dil; a.stride = d->stride; a.pad = d->pad;
+    a.ksize = d->ksize; a.dil = d->dil; a.stride = d->stride; a.pad = d->pad; a.subpix = d->subpixel ? 1 : 0;
     a.k_flat = d->ksize * d->ksize * d->c_in_ld;
     a.magic_c = (unsigned)(4294967296ULL / (unsigned)d->c_in_ld) + 1u;
     a.magic_ks = (unsigned)(4294967296ULL / (unsigned)d->ksize) + 1u;
@@ -355,13 +382,14 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     a.Hs = d->h_in * d->up; a.Ws = d->w_in * d->up;
     a.H = (a.Hs + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
     a.W = (a.Ws + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
+    if (a.subpix) { a.H = d->h_in; a.W = d->w_in; }      // the GEMM's M walks SOURCE pixels, per parity class
     if (a.H <= 0 || a.W <= 0) return BTS_ERR_INVALID;
     a.M = (long)d->B * a.H * a.W;
-    a.n_ntiles = 0;
+    a.n_ntiles = 0; a.tiles_per_class = 0;
     hipStream_t s = (hipStream_t)stream;
     const bool nchw = d->y_nchw != 0;
     int bm, bn;
-    choose_tile(a.M, d->c_out_pad, &bm, &bn);
+    choose_tile(a.M * (a.subpix ? 4 : 1), d->c_out_pad, &bm, &bn);
     static const int w8 = getenv("BTS_CONV_W8") ? atoi(getenv("BTS_CONV_W8")) : 0;
     if (w8) {
         if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4>(a, nchw, s) : launch_conv<64, 128, 2, 2>(a, nchw, s);
@@ -375,8 +403,9 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
 extern "C" int bts_conv_plan_f32(const bts_conv_desc* d, int* bm, int* bn) {
     if (!d || !bm || !bn) return BTS_ERR_INVALID;
     const int Hs = d->h_in * d->up, Ws = d->w_in * d->up;
-    const long H = (Hs + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
-    const long W = (Ws + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
+    long H = (Hs + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
+    long W = (Ws + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
+    if (d->subpixel) { H = 2L * d->h_in; W = 2L * d->w_in; }
     choose_tile((long)d->B * H * W, d->c_out_pad, bm, bn);
     return 0;
 }

@@ -231,6 +231,38 @@ def pack_conv_weight(w: torch.Tensor, perm: Optional[torch.Tensor] = None,
     return out.contiguous(), cout_pad, c_in_ld
 
 
+_SUBPIX_SETS = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}   # (parity, tap) -> 3x3 kernel rows summed
+
+
+def pack_upconv_subpixel(w: torch.Tensor, c_in_ld: Optional[int] = None) -> Tuple[torch.Tensor, int, int]:
+    """upconv = nearest-2x + conv3x3 (reference bts.py:90-92) as four 2x2 convolutions on the source.
+
+    Output pixel (2Y+py, 2X+px) only ever sees source rows {Y-1+py, Y+py} and columns {X-1+px, X+px}: the
+    three kernel rows collapse onto two source rows (py=0: {k0 | k1+k2}, py=1: {k0+k1 | k2}), same for
+    columns.  Returns ([4][cout_pad][k_pad] with class = 2*py+px and k = (ty*2+tx)*c_in_ld + c, cout_pad,
+    c_in_ld).  Zero padding of the upsampled map coincides with source out-of-range, so borders are exact."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    if c_in_ld is None:
+        c_in_ld = round_up(cin, 4)
+    cout_pad = round_up(cout, 32)
+    k_pad = round_up(4 * c_in_ld, 32)
+    wf = w.float()
+    out = torch.zeros((4, cout_pad, k_pad), dtype=torch.float32, device=w.device)
+    for py in (0, 1):
+        for px in (0, 1):
+            blk = torch.zeros((cout_pad, 4, c_in_ld), dtype=torch.float32, device=w.device)
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    acc = None
+                    for ky in _SUBPIX_SETS[(py, ty)]:
+                        for kx in _SUBPIX_SETS[(px, tx)]:
+                            acc = wf[:, :, ky, kx] if acc is None else acc + wf[:, :, ky, kx]
+                    blk[:cout, ty * 2 + tx, :cin] = acc
+            out[2 * py + px, :, :4 * c_in_ld] = blk.reshape(cout_pad, 4 * c_in_ld)
+    return out.contiguous(), cout_pad, c_in_ld
+
+
 def pad_vec(v: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[torch.Tensor]:
     if v is None:
         return None
@@ -254,17 +286,25 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
                  e2: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                  y2d: Optional[torch.Tensor] = None, y_nchw: Optional[torch.Tensor] = None,
                  tag: str = "conv", c_in_real: Optional[int] = None, stride: int = 1, pad: Optional[int] = None,
-                 y2_2d: Optional[torch.Tensor] = None):
+                 y2_2d: Optional[torch.Tensor] = None, subpixel: bool = False):
     """One fused convolution (see bts_conv_desc in include/bts_hip.h).
+    ``subpixel``: w_packed comes from pack_upconv_subpixel; computes nearest-2x + conv3x3 (pass ksize=3, up=2).
 
     x2d: [B*h_in*w_in, C>=c_in_ld] NHWC view.  Exactly one of y2d ([B*H*W, c_out] NHWC view) /
     y_nchw ([B,c_out,H,W] contiguous) receives the result.  pad defaults to dil*(ksize//2)."""
     xs, xc = _rows2d(x2d, "conv_forward")
     _need(w_packed, "conv_forward")
-    c_out_pad, k_pad = w_packed.shape
     if c_in_ld is None:
         c_in_ld = xc
-    taps = ksize * ksize
+    flops_taps = ksize * ksize
+    if subpixel:
+        if ksize != 3 or up != 2 or dil != 1 or stride != 1 or w_packed.dim() != 3 or w_packed.shape[0] != 4:
+            raise BtsHipError("conv_forward: subpixel needs ksize=3, up=2 and weights from pack_upconv_subpixel")
+        _, c_out_pad, k_pad = w_packed.shape
+        taps = 4
+    else:
+        c_out_pad, k_pad = w_packed.shape
+        taps = ksize * ksize
     if k_pad != round_up(taps * c_in_ld, 32) or not w_packed.is_contiguous():
         raise BtsHipError("conv_forward: packed weight [%d,%d] does not match ksize %d / c_in_ld %d"
                           % (c_out_pad, k_pad, ksize, c_in_ld))
@@ -277,6 +317,8 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     d = ConvDesc()
     d.x, d.x_pix_stride, d.c_in_ld, d.k_pad = x2d.data_ptr(), xs, c_in_ld, k_pad
     d.B, d.h_in, d.w_in, d.up, d.ksize, d.dil, d.stride, d.pad = B, h_in, w_in, up, ksize, dil, stride, pad
+    if subpixel:
+        d.up, d.ksize, d.pad, d.subpixel = 1, 2, 0, 1
     d.w, d.c_out, d.c_out_pad = w_packed.data_ptr(), c_out, c_out_pad
     keep = []
     for name, pair, n in (("pre", pre, c_in_ld), ("e1", e1, c_out_pad), ("e2", e2, c_out_pad)):
@@ -311,8 +353,8 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         out = y_nchw
     cin = c_in_real if c_in_real is not None else c_in_ld
     npix_out = B * H * W
-    flops = 2.0 * npix_out * c_out * cin * taps
-    nbytes = 4.0 * (B * h_in * w_in * cin + npix_out * c_out + taps * c_out * cin)
+    flops = 2.0 * npix_out * c_out * cin * flops_taps      # algorithmic: the reference's 3x3 on the upsampled map
+    nbytes = 4.0 * (B * h_in * w_in * cin + npix_out * c_out + flops_taps * c_out * cin)
     variant = "conv"
     if _trace is not None:
         bm, bn = C.c_int(0), C.c_int(0)

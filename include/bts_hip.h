@@ -116,6 +116,11 @@ typedef struct bts_conv_desc {
     float* y;                /* output                                                             */
     long  y_pix_stride;      /* NHWC: floats between pixels; ignored for NCHW                      */
     int   y_nchw;            /* 0: y[p*y_pix_stride + n]; 1: y[(b*c_out + n)*H*W + yx] (boundary)  */
+    int   subpixel;          /* 1: "sub-pixel upconv" -- nearest-2x upsample + 3x3 conv (bts.py:90-92) computed as four
+                                2x2 convolutions on the SOURCE pixels, one per output parity (py,px), 2.25x fewer
+                                FLOPs, same result: requires ksize 2, up 1, stride 1, dil 1, NHWC output;
+                                w = [4][c_out_pad][k_pad] (class = 2*py+px, taps pre-summed, see
+                                bts_amd/ops.py:pack_upconv_subpixel); output is [B, 2*h_in, 2*w_in, c_out]   */
     float* y2;               /* optional second NHWC destination of the same result (a skip tensor
                                 that must live in two concat buffers), or NULL                      */
     long  y2_pix_stride;

@@ -268,6 +268,31 @@ def test_conv_stride_pad_general(ops, cin, cout, k, stride, pad, dil, hw):
     close(ops.nhwc_to_nchw(yb, B, H, W), ref, rtol=1e-4, atol=2e-5, what="conv k%d s%d" % (k, stride))
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(64, 32, (2, 9, 14)), (128, 128, (1, 5, 7)), (2208, 96, (2, 3, 4)),
+                                            (36, 64, (3, 1, 1)), (48, 256, (1, 11, 2))])
+def test_upconv_subpixel(ops, cin, cout, shape):
+    """nearest-2x + conv3x3 + ELU + BN (upconv + bn, bts.py:83-94, 226-227) via the 4-class 2x2 decomposition,
+    including 1-pixel-wide maps (every output touches the zero padding)."""
+    B, h, w = shape
+    rng = np.random.Generator(np.random.PCG64(cin + cout))
+    x = rng.standard_normal(size=(B, cin, h, w), dtype=np.float32)
+    wt = (rng.standard_normal(size=(cout, cin, 3, 3)) * 0.05).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, size=cout).astype(np.float32)
+    sh = (rng.standard_normal(size=cout) * 0.1).astype(np.float32)
+    ref = F.elu(F.conv2d(F.interpolate(torch.from_numpy(x), scale_factor=2, mode="nearest"), torch.from_numpy(wt), padding=1))
+    ref = ref * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1)
+    xin = torch.zeros(B * h * w, cin, device="cuda")
+    ops.nchw_to_nhwc(dev(x), xin)
+    wp, cop, cld = ops.pack_upconv_subpixel(dev(wt))
+    e2 = (dev(ops.pad_vec(torch.from_numpy(sc), cop, 1.0)), dev(ops.pad_vec(torch.from_numpy(sh), cop, 0.0)))
+    yb = torch.full((B * 4 * h * w, cout + 4), -3.0, device="cuda")
+    ops.conv_forward(xin, B, h, w, wp, cout, 3, up=2, act=ops.ACT_ELU, e2=e2, y2d=yb[:, 4:], subpixel=True)
+    assert (yb[:, :4] == -3.0).all()
+    # K up to 4*2208 with pre-summed taps: tolerance relative to the output scale (fp32 rounding ~ sqrt(K)*eps)
+    close(ops.nhwc_to_nchw(yb[:, 4:], B, 2 * h, 2 * w), ref, rtol=1e-4, atol=2e-5 * max(1.0, float(ref.abs().max())),
+          what="subpixel upconv %d->%d" % (cin, cout))
+
+
 def test_conv_k_permutation(ops):
     """pack_conv_weight(perm=...) lets the NHWC buffer keep its own channel order."""
     B, h, w, cin, cout = 1, 6, 8, 48, 32
