@@ -103,7 +103,7 @@ __device__ __forceinline__ void issue_loads(const ConvArgs& a, const float* __re
 }
 
 // Prologue (BN affine + ReLU, reference bts.py:70,72) and zero padding, applied on the way to LDS.
-template <int BM, int RPP, int PA, int PB>
+template <int BM, int BN, int RPP, int PA, int PB>
 __device__ __forceinline__ void stage_to_lds(const ConvArgs& a, float* __restrict__ As, int lrow, int lk,
                                              const f32x4 (&ra)[PA], const f32x4 (&rb)[PB], const f32x4& ps,
                                              const f32x4& pb, unsigned okmask) {
@@ -121,15 +121,22 @@ __device__ __forceinline__ void stage_to_lds(const ConvArgs& a, float* __restric
         *reinterpret_cast<f32x4*>(As + (p * RPP + lrow) * LDS_LD + lk) = v;
     }
 #pragma unroll
-    for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(Bs + (p * RPP + lrow) * LDS_LD + lk) = rb[p];
+    for (int p = 0; p < PB; ++p)
+        if ((p + 1) * RPP <= BN || p * RPP + lrow < BN)       // BN = 48: the last pass covers half its rows
+            *reinterpret_cast<f32x4*>(Bs + (p * RPP + lrow) * LDS_LD + lk) = rb[p];
 }
 
-template <int BM, int BN, int WM, int WN, bool NCHW_OUT>
+// MF = 32: v_mfma_f32_32x32x2_f32 tiles (default).  MF = 16: v_mfma_f32_16x16x4_f32 tiles, same FLOP rate
+// but 16-column granularity -- used for c_out = 48 (DenseNet growth) where a 64-wide tile wastes 25 %.
+template <int BM, int BN, int WM, int WN, int MF, bool NCHW_OUT>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a) {
     constexpr int NT = WM * WN * 64;          // threads per workgroup (4 or 8 waves)
     constexpr int RPP = NT / 8;               // tile rows staged per pass (8 lanes x 16 B per row)
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int TM = BM / WM / MF, TN = BN / WN / MF;
+    constexpr int PA = BM / RPP, PB = (BN + RPP - 1) / RPP;
+    constexpr int NACC = MF == 32 ? 16 : 4;   // accumulator registers per tile
+    typedef float acc_t __attribute__((ext_vector_type(NACC)));
+    static_assert(BM % RPP == 0 && BM % (WM * MF) == 0 && BN % (WN * MF) == 0, "tile/wave layout");
     constexpr int STAGE_AT = CONV_STAGE_AT;   // g-step after which the next tile is written to LDS (0..3)
     static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "tile/wave layout");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -188,18 +195,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
 
     const int wv = tid >> 6, lane = tid & 63;
     const int wm = wv / WN, wn = wv % WN;
-    const int li = lane & 31, lh = lane >> 5;
+    // fragment coordinates: lane = (li, lh); MF 32: li = row in tile (0..31), lh = k half (0..1);
+    //                                        MF 16: li = row in tile (0..15), lh = k quarter (0..3)
+    const int li = lane & (MF - 1), lh = lane / MF;
 
-    f32x16 acc[TM][TN];
+    acc_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < NACC; ++r) acc[i][j][r] = 0.f;
 
     issue_loads<PA, PB>(a, wbase, pad_y, pad_x, 0, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
-    stage_to_lds<BM, RPP, PA, PB>(a, smem, lrow, lk, ra, rb, ps, pb, okmask);
+    stage_to_lds<BM, BN, RPP, PA, PB>(a, smem, lrow, lk, ra, rb, ps, pb, okmask);
     __syncthreads();
 
     for (int it = 0; it < nit; ++it) {
@@ -207,15 +216,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
         const bool more = it + 1 < nit;
         if (more) issue_loads<PA, PB>(a, wbase, pad_y, pad_x, it + 1, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
 
-        const float* As = smem + buf * BUF_FLOATS + (wm * TM * 32 + li) * LDS_LD + 4 * lh;
-        const float* Bs = smem + buf * BUF_FLOATS + BM * LDS_LD + (wn * TN * 32 + li) * LDS_LD + 4 * lh;
+        const float* As = smem + buf * BUF_FLOATS + (wm * TM * MF + li) * LDS_LD + 4 * lh;
+        const float* Bs = smem + buf * BUF_FLOATS + BM * LDS_LD + (wn * TN * MF + li) * LDS_LD + 4 * lh;
+        constexpr int KG = 256 / MF;              // k covered by one ds_read_b128 per lane set: 8 (MF 32) / 16 (MF 16)
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
+        for (int g = 0; g < BK / KG; ++g) {
             f32x4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + 8 * g);
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + i * MF * LDS_LD + KG * g);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + 8 * g);
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * MF * LDS_LD + KG * g);
             // q outermost: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -223,33 +233,38 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if (NCHW_OUT) acc[i][j] = mfma32x2(fb[j][q], fa[i][q], acc[i][j]);   // rows = channels, lanes = pixels
-                        else          acc[i][j] = mfma32x2(fa[i][q], fb[j][q], acc[i][j]);   // rows = pixels, lanes = channels
+                        // NCHW_OUT: rows = channels, lanes = pixels; else rows = pixels, lanes = channels
+                        const float ra_ = NCHW_OUT ? fb[j][q] : fa[i][q];
+                        const float rb_ = NCHW_OUT ? fa[i][q] : fb[j][q];
+                        if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_, rb_, acc[i][j], 0, 0, 0);
+                        else                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra_, rb_, acc[i][j], 0, 0, 0);
                     }
             // The next tile's registers go to the OTHER LDS buffer half-way through this tile's MFMAs: by now
             // its loads (issued before g = 0) have landed, and the waits / prologue VALU / ds_writes can issue
             // in the shadow of the remaining MFMAs instead of after them.
-            if (g == STAGE_AT && more)
-                stage_to_lds<BM, RPP, PA, PB>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
+            if (g == (STAGE_AT < BK / KG ? STAGE_AT : BK / KG - 1) && more)
+                stage_to_lds<BM, BN, RPP, PA, PB>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
         }
         __syncthreads();
     }
 
     // ---------------------------------------------------------------- epilogue
+    // D register r of lane (li, lh) is D[row][col = li] with row = (r&3) + 8*(r>>2) + 4*lh (MF 32) or 4*lh + r (MF 16)
     const bool has_e1 = a.e1_scale != nullptr, has_e2 = a.e2_scale != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (!NCHW_OUT) {
-                const int n = n0 + (wn * TN + j) * 32 + li;
+                const int n = n0 + (wn * TN + j) * MF + li;
                 float s1 = 1.f, b1 = 0.f, s2 = 1.f, b2 = 0.f;
                 const bool nok = n < a.c_out;
                 if (has_e1 && n < a.c_out_pad) { s1 = a.e1_scale[n]; b1 = a.e1_shift[n]; }
                 if (has_e2 && n < a.c_out_pad) { s2 = a.e2_scale[n]; b2 = a.e2_shift[n]; }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                for (int r = 0; r < NACC; ++r) {
+                    const int drow = MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * lh : 4 * lh + r;
+                    const long m = m0 + (wm * TM + i) * MF + drow;
                     float v = acc[i][j][r];
                     if (has_e1) v = v * s1 + b1;
                     v = apply_act(v, a.act);
@@ -266,13 +281,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
                     }
                 }
             } else {
-                const long m = m0 + (wm * TM + i) * 32 + li;
+                const long m = m0 + (wm * TM + i) * MF + li;
                 const bool mok = m < a.M;
                 const long mm = mok ? m : 0;
                 const long b = mm / HW, yx = mm % HW;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + (wn * TN + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                for (int r = 0; r < NACC; ++r) {
+                    const int drow = MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * lh : 4 * lh + r;
+                    const int n = n0 + (wn * TN + j) * MF + drow;
                     float v = acc[i][j][r];
                     if (n < a.c_out_pad) {
                         if (has_e1) v = v * a.e1_scale[n] + a.e1_shift[n];
@@ -285,25 +301,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
         }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MF = 32>
 int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s) {
     ConvArgs a = a0;
     const long n_mtiles = (a.M + BM - 1) / BM;
-    a.n_ntiles = (a.c_out_pad + BN - 1) / BN;
+    a.n_ntiles = (a.c_out + BN - 1) / BN;            // tiles over REAL channels; wrow clamps into c_out_pad
     a.tiles_per_class = (int)(n_mtiles * a.n_ntiles);
     const long nwg = n_mtiles * a.n_ntiles * (a.subpix ? 4 : 1);
     if (nwg > 0x7fffffffL) return BTS_ERR_INVALID;
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    if (const char* f = getenv("BTS_CONV_LDS_KB")) {   // tuning aid: inflate LDS to limit workgroups per CU
+        const size_t v = (size_t)atoi(f) * 1024;
+        if (v > lds && v <= 160 * 1024) lds = v;
+    }
     hipError_t e;
     if (nchw) {
-        auto k = conv_fwd_kernel<BM, BN, WM, WN, true>;
+        auto k = conv_fwd_kernel<BM, BN, WM, WN, MF, true>;
         if (lds > 64 * 1024) {
             e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, a);
     } else {
-        auto k = conv_fwd_kernel<BM, BN, WM, WN, false>;
+        auto k = conv_fwd_kernel<BM, BN, WM, WN, MF, false>;
         if (lds > 64 * 1024) {
             e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
@@ -316,18 +336,20 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s) {
 // Tile choice.  BN follows c_out; BM trades per-tile efficiency against wave quantisation: the chip
 // finishes ceil(n_wg / 256 CUs) "tile rounds", so 836 tiles of 128 rows cost 4 rounds (82 % busy)
 // while 1672 tiles of 64 rows cost 7 half-rounds (93 %).  The 64-row tile pays ~5 % more staging.
-void choose_tile(long M, int c_out_pad, int* bm, int* bn) {
-    // BN: least padded width, weighted by how well each tile shape runs (128: 1.0, 64: 1.05, 32: 1.2)
-    const int cand[3] = {128, 64, 32};
-    const double eff[3] = {1.0, 1.05, 1.2};
+void choose_tile(long M, int c_out, int* bm, int* bn) {
+    // BN: least padded width, weighted by how well each tile shape runs.  48 = three 16x16x4 MFMA tiles.
+    const int cand[4] = {128, 64, 32, 48};
+    const double eff[4] = {1.0, 1.05, 1.2, 1.12};
     double best = 1e30;
-    for (int i = 0; i < 3; ++i) {
-        const double cost = (double)((c_out_pad + cand[i] - 1) / cand[i] * cand[i]) * eff[i];
+    for (int i = 0; i < 4; ++i) {
+        if (cand[i] == 48 && c_out % 48 != 0) continue;
+        const double cost = (double)((c_out + cand[i] - 1) / cand[i] * cand[i]) * eff[i];
         if (cost < best) { best = cost; *bn = cand[i]; }
     }
+    if (const char* f = getenv("BTS_CONV_NO48")) { if (atoi(f) && *bn == 48) *bn = 64; }
     *bm = 128;
     if (*bn != 32) {
-        const long nt = (c_out_pad + *bn - 1) / *bn;
+        const long nt = (c_out + *bn - 1) / *bn;
         const long wg128 = ((M + 127) / 128) * nt, wg64 = ((M + 63) / 64) * nt;
         const double t128 = (double)((wg128 + 255) / 256) * 128.0;
         const double t64 = (double)((wg64 + 255) / 256) * 64.0 * 1.05;
@@ -389,7 +411,8 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool nchw = d->y_nchw != 0;
     int bm, bn;
-    choose_tile(a.M * (a.subpix ? 4 : 1), d->c_out_pad, &bm, &bn);
+    choose_tile(a.M * (a.subpix ? 4 : 1), d->c_out, &bm, &bn);
+    if (bn == 48) return bm == 128 ? launch_conv<128, 48, 4, 1, 16>(a, nchw, s) : launch_conv<64, 48, 4, 1, 16>(a, nchw, s);
     static const int w8 = getenv("BTS_CONV_W8") ? atoi(getenv("BTS_CONV_W8")) : 0;
     if (w8) {
         if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4>(a, nchw, s) : launch_conv<64, 128, 2, 2>(a, nchw, s);
@@ -406,6 +429,6 @@ extern "C" int bts_conv_plan_f32(const bts_conv_desc* d, int* bm, int* bn) {
     long H = (Hs + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
     long W = (Ws + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
     if (d->subpixel) { H = 2L * d->h_in; W = 2L * d->w_in; }
-    choose_tile((long)d->B * H * W, d->c_out_pad, bm, bn);
+    choose_tile((long)d->B * H * W, d->c_out, bm, bn);
     return 0;
 }

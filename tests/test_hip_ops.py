@@ -293,6 +293,35 @@ def test_upconv_subpixel(ops, cin, cout, shape):
           what="subpixel upconv %d->%d" % (cin, cout))
 
 
+@pytest.mark.parametrize("shape,nchw", [((2, 13, 17), False), ((1, 40, 52), False), ((3, 7, 5), True)])
+def test_conv_growth48_mfma16(ops, shape, nchw):
+    """DenseNet dense-layer 3x3 (192 -> 48): runs on the 16x16x4-MFMA tile variant (BN = 48), ragged M,
+    NHWC slice and NCHW outputs, with a BN+ReLU prologue and an ELU epilogue."""
+    B, h, w = shape
+    cin, cout = 192, 48
+    rng = np.random.Generator(np.random.PCG64(h * 31 + w))
+    x = rng.standard_normal(size=(B, cin, h, w), dtype=np.float32)
+    wt = (rng.standard_normal(size=(cout, cin, 3, 3)) * 0.03).astype(np.float32)
+    ps = rng.uniform(0.5, 1.5, size=cin).astype(np.float32)
+    pb = (rng.standard_normal(size=cin) * 0.2).astype(np.float32)
+    xt = torch.from_numpy(x)
+    ref = F.elu(F.conv2d(F.relu(xt * torch.from_numpy(ps).view(1, -1, 1, 1) + torch.from_numpy(pb).view(1, -1, 1, 1)),
+                         torch.from_numpy(wt), padding=1))
+    xin = torch.zeros(B * h * w, cin, device="cuda")
+    ops.nchw_to_nhwc(dev(x), xin)
+    wp, cop, cld = ops.pack_conv_weight(dev(wt))
+    pre = (dev(ps), dev(pb))
+    if nchw:
+        y = torch.empty(B, cout, h, w, device="cuda")
+        ops.conv_forward(xin, B, h, w, wp, cout, 3, pre=pre, pre_relu=True, act=ops.ACT_ELU, y_nchw=y)
+    else:
+        yb = torch.full((B * h * w, cout + 16), 9.0, device="cuda")
+        ops.conv_forward(xin, B, h, w, wp, cout, 3, pre=pre, pre_relu=True, act=ops.ACT_ELU, y2d=yb[:, 8:56])
+        assert (yb[:, :8] == 9.0).all() and (yb[:, 56:] == 9.0).all()
+        y = ops.nhwc_to_nchw(yb[:, 8:56], B, h, w)
+    close(y, ref, rtol=1e-4, atol=2e-5, what="growth-48 conv")
+
+
 def test_conv_k_permutation(ops):
     """pack_conv_weight(perm=...) lets the NHWC buffer keep its own channel order."""
     B, h, w, cin, cout = 1, 6, 8, 48, 32
