@@ -54,6 +54,27 @@ def build_model(params, device, seed=0):
     return model.eval().to(device)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json:
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command); None if absent.
+    Counters cannot be collected from inside the benchmark process itself."""
+    import glob
+    import re
+    m = re.match(r"conv_fwd_kernel<(\d+),(\d+),(nhwc|nchw)>", kernel)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not m or not files:
+        return None
+    try:
+        tab = json.load(open(files[-1]))
+    except Exception:
+        return None
+    for k, v in tab.items():
+        mm = re.match(r"conv_fwd_kernel<(\d+),(\d+),\d+,\d+,\d+,(false|true)>", k)
+        if mm and mm.group(1) == m.group(1) and mm.group(2) == m.group(2) and (mm.group(3) == "true") == (m.group(3) == "nchw"):
+            return {"hbm_bytes_per_launch": int(v["hbm_MB_per_launch"] * 1e6), "source": os.path.basename(files[-1])}
+    return None
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box
     exposes all host cores to os.cpu_count() but grants a 1-GPU job a share of them)."""
@@ -111,6 +132,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step all-gather of the 5 depth maps (N>1)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="run the per-GPU batch as this many concurrent sub-batches on separate HIP streams (one graph): "
+                         "frames are independent, so under-filled launches of one sub-batch overlap the other's")
     ap.add_argument("--decoder-only", action="store_true", help="time only the decoder hot path on encoder-shaped features")
     ap.add_argument("--encoder-backend", choices=["hip", "aten", "miopen"], default="hip",
                     help="hip: DenseNet encoder on the HIP conv kernel (default); aten: torch encoder on ATen's native "
@@ -136,10 +160,20 @@ def main():
     params = Params(args.encoder, 512, 80.0 if is_kitti else 10.0, "kitti" if is_kitti else "nyu")
     B, H, W = args.batch, args.height, args.width
     log("building model %s" % args.encoder)
+    S = max(1, args.streams)
+    assert B % S == 0, "--batch must be divisible by --streams"
     model = build_model(params, device, seed=0)
     model.native_encoder = args.encoder_backend == "hip"
     bdist.broadcast_module(model, src=0)            # RCCL broadcast of ~188 MB, once
-    log("model on %s" % device)
+    # one replica (own NHWC workspaces, same weights) per concurrent sub-batch
+    replicas = [model]
+    for _ in range(1, S):
+        r = build_model(params, device, seed=0)
+        r.load_state_dict(model.state_dict())
+        r.native_encoder = model.native_encoder
+        replicas.append(r)
+    sub_streams = [torch.cuda.Stream(device) for _ in range(S)] if S > 1 else []
+    log("model on %s (%d sub-batch stream%s)" % (device, S, "s" if S > 1 else ""))
 
     image = torch.from_numpy(synth.image_batch(B, H, W, 1234 + rank)).to(device)
     focal = torch.from_numpy(synth.focal_values(B, params.dataset, 1234 + rank)).to(device)
@@ -148,10 +182,23 @@ def main():
         fe = synth.encoder_features(synth.ENCODER_CHANNELS[args.encoder], B, H, W, 1234 + rank)
         feats_static = [None] + [torch.from_numpy(f).to(device) for f in fe[1:]]
 
-    def forward():
+    def forward_one(m, lo, hi):
         if feats_static is not None:
-            return model.decoder(feats_static, focal)
-        return model(image, focal)
+            return m.decoder([None] + [f[lo:hi] for f in feats_static[1:]], focal[lo:hi])
+        return m(image[lo:hi], focal[lo:hi])
+
+    def forward():
+        if S == 1:
+            return forward_one(model, 0, B)
+        cur = torch.cuda.current_stream()
+        parts = []
+        for i, (m, st) in enumerate(zip(replicas, sub_streams)):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                parts.append(forward_one(m, i * (B // S), (i + 1) * (B // S)))
+        for st in sub_streams:
+            cur.wait_stream(st)
+        return tuple(torch.cat([p[j] for p in parts], 0) for j in range(6))
 
     use_graph = not args.no_graph
     graph, outs = None, None
@@ -230,7 +277,7 @@ def main():
             d = summ[dom]
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": pmc_traffic(dom),
                     "launches_per_step": d["launches"] // nrep,
                     "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                     "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
@@ -279,7 +326,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "image": "%dx%d" % (H, W),
                        "parallelism": "dp%d batch-sharded, RCCL weight broadcast once%s" % (
                            world, ", all-gather of 5 depth maps per step" if gather else ""),
-                       "hipgraph": graph is not None, "encoder_backend": args.encoder_backend,
+                       "hipgraph": graph is not None, "sub_batch_streams": S, "encoder_backend": args.encoder_backend,
                        "weights": "random-init encoder + PCG64(0) synthetic decoder"},
             "roofline": roof,
         }

@@ -28,9 +28,6 @@
 
 namespace {
 
-#ifndef CONV_STAGE_AT
-#define CONV_STAGE_AT 1
-#endif
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
 
@@ -102,6 +99,40 @@ __device__ __forceinline__ void issue_loads(const ConvArgs& a, const float* __re
     for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(wbase + (wofs + wrow[p]));
 }
 
+// Lean loader for the common case c_in_ld % 32 == 0 and no folded upsample: the whole K-step then sits
+// in ONE tap, so tap decode and the tap's spatial offset are wave-uniform (SALU), the bounds checks collapse
+// to one precomputed per-row bitmask over taps, and each row's address is base[p] + (ok ? delta : c).
+// Per-wave VALU between MFMAs is the main tax on MFMA issue (scripts/ubench/mfma_ablate.cpp), so this
+// matters more than it looks: ~5 VALU per staged row instead of ~20.
+template <int PA, int PB>
+__device__ __forceinline__ void issue_loads_fast(const ConvArgs& a, const float* __restrict__ wbase, int pad_y, int pad_x,
+                                                 int it, int tap, int kc, const unsigned (&abase)[PA],
+                                                 const unsigned long long (&vmask)[PA], const unsigned (&wrow)[PB],
+                                                 f32x4 (&ra)[PA], f32x4 (&rb)[PB], f32x4& ps, f32x4& pb,
+                                                 unsigned& okmask, int lk) {
+    const int ky = tap / a.ksize, kx = tap - ky * a.ksize;                 // scalar
+    const int dy = ky * a.dil - pad_y, dx = kx * a.dil - pad_x;
+    const int c0 = kc * BK;
+    const unsigned d_c = (unsigned)c0;
+    const unsigned d_full = (unsigned)((dy * a.w_in + dx) * (int)a.x_pix_stride + c0);
+    if (a.pre_scale != nullptr) {
+        ps = *reinterpret_cast<const f32x4*>(a.pre_scale + c0 + lk);
+        pb = *reinterpret_cast<const f32x4*>(a.pre_shift + c0 + lk);
+    }
+    unsigned m = 0;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const unsigned ok = (unsigned)(vmask[p] >> tap) & 1u;
+        const unsigned off = abase[p] + (ok ? d_full : d_c);
+        ra[p] = *reinterpret_cast<const f32x4*>(a.x + off);
+        m |= ok << p;
+    }
+    okmask = m;
+    const unsigned wofs = (unsigned)(it * BK);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(wbase + (wofs + wrow[p]));
+}
+
 // Prologue (BN affine + ReLU, reference bts.py:70,72) and zero padding, applied on the way to LDS.
 template <int BM, int BN, int RPP, int PA, int PB>
 __device__ __forceinline__ void stage_to_lds(const ConvArgs& a, float* __restrict__ As, int lrow, int lk,
@@ -137,7 +168,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     constexpr int NACC = MF == 32 ? 16 : 4;   // accumulator registers per tile
     typedef float acc_t __attribute__((ext_vector_type(NACC)));
     static_assert(BM % RPP == 0 && BM % (WM * MF) == 0 && BN % (WN * MF) == 0, "tile/wave layout");
-    constexpr int STAGE_AT = CONV_STAGE_AT;   // g-step after which the next tile is written to LDS (0..3)
     static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "tile/wave layout");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
@@ -179,6 +209,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
         ax[p] = (yx % a.W) * a.stride;
         abase[p] = (unsigned)b * (unsigned)(a.h_in * a.w_in);
     }
+    // lean-loader state: centre-pixel element offset (+ lane channel) and a tap-validity bitmask per row
+    const bool fastk = (a.c_in_ld % BK) == 0 && a.ups == 0;
+    unsigned fbase[PA];
+    unsigned long long vmask[PA];
+    const int kchunks = a.c_in_ld / BK;          // K-steps per tap (lean path)
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        fbase[p] = (abase[p] + (unsigned)(ay[p] * a.w_in + ax[p])) * (unsigned)a.x_pix_stride + (unsigned)lk;
+        unsigned long long vm = 0;
+        if (fastk && ((avalid >> p) & 1u)) {
+            for (int t = 0; t < a.ksize * a.ksize; ++t) {
+                const int ky = t / a.ksize, kx = t - ky * a.ksize;
+                const int yy = ay[p] + ky * a.dil - pad_y, xx = ax[p] + kx * a.dil - pad_x;
+                if ((unsigned)yy < (unsigned)a.Hs && (unsigned)xx < (unsigned)a.Ws) vm |= 1ull << t;
+            }
+        }
+        vmask[p] = vm;
+    }
     unsigned wrow[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
@@ -207,25 +255,44 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
 #pragma unroll
             for (int r = 0; r < NACC; ++r) acc[i][j][r] = 0.f;
 
-    issue_loads<PA, PB>(a, wbase, pad_y, pad_x, 0, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
+    // Prefetch distance 2 with ONE staging register set: during step `it` the registers hold tile it+1 (its loads
+    // were issued a full step ago, so they have landed even on an HBM miss): write it to the other LDS buffer,
+    // then reuse the registers for the loads of tile it+2, which get a whole step of MFMAs to arrive.
+    int tap = 0, kc = 0;                          // lean path: (tap, channel chunk) of the K-step being loaded
+    auto issue = [&](int t) {
+        if (fastk) {
+            if (t > 0 && ++kc == kchunks) { kc = 0; ++tap; }
+            issue_loads_fast<PA, PB>(a, wbase, pad_y, pad_x, t, tap, kc, fbase, vmask, wrow, ra, rb, ps, pb, okmask, lk);
+        } else {
+            issue_loads<PA, PB>(a, wbase, pad_y, pad_x, t, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
+        }
+    };
+    issue(0);
     stage_to_lds<BM, BN, RPP, PA, PB>(a, smem, lrow, lk, ra, rb, ps, pb, okmask);
+    if (nit > 1) issue(1);
     __syncthreads();
+
+    constexpr int KG = 256 / MF;              // k covered by one ds_read_b128 per lane set: 8 (MF 32) / 16 (MF 16)
+    constexpr int NG = BK / KG;               // fragment groups per K-step: 4 / 2
+    const int a_off = (wm * TM * MF + li) * LDS_LD + 4 * lh;
+    const int b_off = BM * LDS_LD + (wn * TN * MF + li) * LDS_LD + 4 * lh;
+    // Fragments are double-buffered in registers: group g+1 is read from LDS while group g's MFMAs issue, and
+    // the first group of the NEXT K-step is read right after the barrier.
+    f32x4 fa[2][TM], fb[2][TN];
+    auto read_frags = [&](const float* base, int g, int slot) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(base + a_off + i * MF * LDS_LD + KG * g);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4*>(base + b_off + j * MF * LDS_LD + KG * g);
+    };
+    read_frags(smem, 0, 0);
 
     for (int it = 0; it < nit; ++it) {
         const int buf = it & 1;
-        const bool more = it + 1 < nit;
-        if (more) issue_loads<PA, PB>(a, wbase, pad_y, pad_x, it + 1, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
-
-        const float* As = smem + buf * BUF_FLOATS + (wm * TM * MF + li) * LDS_LD + 4 * lh;
-        const float* Bs = smem + buf * BUF_FLOATS + BM * LDS_LD + (wn * TN * MF + li) * LDS_LD + 4 * lh;
-        constexpr int KG = 256 / MF;              // k covered by one ds_read_b128 per lane set: 8 (MF 32) / 16 (MF 16)
+        const float* cur = smem + buf * BUF_FLOATS;
 #pragma unroll
-        for (int g = 0; g < BK / KG; ++g) {
-            f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + i * MF * LDS_LD + KG * g);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * MF * LDS_LD + KG * g);
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) read_frags(cur, g + 1, (g + 1) & 1);
             // q outermost: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -234,18 +301,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         // NCHW_OUT: rows = channels, lanes = pixels; else rows = pixels, lanes = channels
-                        const float ra_ = NCHW_OUT ? fb[j][q] : fa[i][q];
-                        const float rb_ = NCHW_OUT ? fa[i][q] : fb[j][q];
+                        const float ra_ = NCHW_OUT ? fb[g & 1][j][q] : fa[g & 1][i][q];
+                        const float rb_ = NCHW_OUT ? fa[g & 1][i][q] : fb[g & 1][j][q];
                         if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_, rb_, acc[i][j], 0, 0, 0);
                         else                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra_, rb_, acc[i][j], 0, 0, 0);
                     }
-            // The next tile's registers go to the OTHER LDS buffer half-way through this tile's MFMAs: by now
-            // its loads (issued before g = 0) have landed, and the waits / prologue VALU / ds_writes can issue
-            // in the shadow of the remaining MFMAs instead of after them.
-            if (g == (STAGE_AT < BK / KG ? STAGE_AT : BK / KG - 1) && more)
-                stage_to_lds<BM, BN, RPP, PA, PB>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
+            if (g == 0) {     // after the first MFMA group: the staging VALU / ds_writes / address math issue in the
+                              // shadow of the remaining groups; the new loads still get ~a full step to land
+                if (it + 1 < nit) stage_to_lds<BM, BN, RPP, PA, PB>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
+                if (it + 2 < nit) issue(it + 2);
+            }
         }
         __syncthreads();
+        if (it + 1 < nit) read_frags(smem + (buf ^ 1) * BUF_FLOATS, 0, 0);
     }
 
     // ---------------------------------------------------------------- epilogue
