@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step all-gather of the 5 depth maps (N>1)")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="run the per-GPU batch as this many concurrent sub-batches on separate HIP streams (one graph): "
                          "frames are independent, so under-filled launches of one sub-batch overlap the other's")
     ap.add_argument("--decoder-only", action="store_true", help="time only the decoder hot path on encoder-shaped features")
@@ -164,16 +164,9 @@ def main():
     assert B % S == 0, "--batch must be divisible by --streams"
     model = build_model(params, device, seed=0)
     model.native_encoder = args.encoder_backend == "hip"
+    model.sub_batches = S
     bdist.broadcast_module(model, src=0)            # RCCL broadcast of ~188 MB, once
-    # one replica (own NHWC workspaces, same weights) per concurrent sub-batch
-    replicas = [model]
-    for _ in range(1, S):
-        r = build_model(params, device, seed=0)
-        r.load_state_dict(model.state_dict())
-        r.native_encoder = model.native_encoder
-        replicas.append(r)
-    sub_streams = [torch.cuda.Stream(device) for _ in range(S)] if S > 1 else []
-    log("model on %s (%d sub-batch stream%s)" % (device, S, "s" if S > 1 else ""))
+    log("model on %s (%d concurrent sub-batch%s)" % (device, S, "es" if S > 1 else ""))
 
     image = torch.from_numpy(synth.image_batch(B, H, W, 1234 + rank)).to(device)
     focal = torch.from_numpy(synth.focal_values(B, params.dataset, 1234 + rank)).to(device)
@@ -182,23 +175,10 @@ def main():
         fe = synth.encoder_features(synth.ENCODER_CHANNELS[args.encoder], B, H, W, 1234 + rank)
         feats_static = [None] + [torch.from_numpy(f).to(device) for f in fe[1:]]
 
-    def forward_one(m, lo, hi):
-        if feats_static is not None:
-            return m.decoder([None] + [f[lo:hi] for f in feats_static[1:]], focal[lo:hi])
-        return m(image[lo:hi], focal[lo:hi])
-
     def forward():
-        if S == 1:
-            return forward_one(model, 0, B)
-        cur = torch.cuda.current_stream()
-        parts = []
-        for i, (m, st) in enumerate(zip(replicas, sub_streams)):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                parts.append(forward_one(m, i * (B // S), (i + 1) * (B // S)))
-        for st in sub_streams:
-            cur.wait_stream(st)
-        return tuple(torch.cat([p[j] for p in parts], 0) for j in range(6))
+        if feats_static is not None:
+            return model.decoder(feats_static, focal)
+        return model(image, focal)
 
     use_graph = not args.no_graph
     graph, outs = None, None
@@ -269,8 +249,10 @@ def main():
             tr = ops.KernelTrace()
             ops.set_trace(tr)
             nrep = max(3, min(args.steps, 10))
+            model.sub_batches = 1       # kernels timed in isolation (concurrent sub-batches share the chip)
             for _ in range(nrep):
                 forward()
+            model.sub_batches = S
             ops.set_trace(None)
             summ = tr.summary()
             dom = max((k for k in summ if k.startswith("conv_fwd_kernel")), key=lambda k: summ[k]["ms"])

@@ -348,8 +348,8 @@ class bts(nn.Module):
         return P
 
     # ------------------------------------------------------------------ NHWC workspace (per shape)
-    def _workspace(self, B: int, H: int, W: int, device) -> Dict[str, torch.Tensor]:
-        key = (B, H, W, str(device))
+    def _workspace(self, B: int, H: int, W: int, device, slot: int = 0) -> Dict[str, torch.Tensor]:
+        key = (B, H, W, str(device), slot)
         ws = self._bufs.get(key)
         if ws is not None:
             return ws
@@ -376,7 +376,7 @@ class bts(nn.Module):
             plane2=z(n2, 4),
             cat1=z(n1, nf // 16 + 4),                            # [upconv1 | reduc1x1 d2 d4 d8]
         )
-        if len(self._bufs) >= 4:
+        if len(self._bufs) >= 8:
             self._bufs.clear()
         self._bufs[key] = ws
         return ws
@@ -403,10 +403,11 @@ class bts(nn.Module):
             ops.nchw_to_nhwc(src, dst)
         return self.forward_nhwc(ws, B, H, W, focal, ws["f5"], None, False)
 
-    def forward_nhwc(self, ws, B, H, W, focal, dense2d, dense_pre, dense_relu):
+    def forward_nhwc(self, ws, B, H, W, focal, dense2d, dense_pre, dense_relu, outs=None):
         """The decoder proper on NHWC buffers.  ``ws``: this module's workspace with the four skip slots
         already filled; ``dense2d``: the 1/32-resolution features [npix, C>=f[4]] and the prologue
-        (affine, relu) still to be applied to them (norm5 + ReLU when the encoder is fused in)."""
+        (affine, relu) still to be applied to them (norm5 + ReLU when the encoder is fused in).
+        ``outs``: optional 6 preallocated contiguous result tensors (e.g. batch slices of full-batch tensors)."""
         _require_eval(self, "bts")
         dev = dense2d.device
         nf, f = self.num_features, self.feat_out_channels
@@ -445,9 +446,17 @@ class bts(nn.Module):
         def am():
             return torch.empty((), dtype=torch.float32, device=dev)
 
+        def out_tensor(i, c):
+            if outs is not None:
+                t = outs[i]
+                if tuple(t.shape) != (B, c, H, W) or not t.is_contiguous():
+                    raise BtsHipError("forward_nhwc: outs[%d] must be contiguous [%d,%d,%d,%d]" % (i, B, c, H, W))
+                return t
+            return torch.empty((B, c, H, W), dtype=torch.float32, device=dev)
+
         # 8x8 scale (bts.py:249-256)
         self.reduc8x8.run_nhwc(ws["daspp_feat"], ws["plane8"], True)
-        depth_8x8_scaled = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        depth_8x8_scaled = out_tensor(0, 1)
         a8 = am()
         c3 = ws["cat3"]
         ops.lpg_fused_forward(ws["plane8"], B, h8, w8, 8, md, False, depth_8x8_scaled,
@@ -458,7 +467,7 @@ class bts(nn.Module):
         conv(self.upconv3.packed(), ws["daspp_feat"], h8, w8, q, y2d=c3[:, :q], up=2, e2=P["bn3"])
         conv("conv3", c3, h4, w4, q, y2d=ws["iconv3"], c_in_real=q + f[1] + 1)
         self.reduc4x4.run_nhwc(ws["iconv3"], ws["plane4"], True)
-        depth_4x4_scaled = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        depth_4x4_scaled = out_tensor(1, 1)
         a4 = am()
         c2 = ws["cat2"]
         ops.lpg_fused_forward(ws["plane4"], B, h4, w4, 4, md, False, depth_4x4_scaled,
@@ -469,7 +478,7 @@ class bts(nn.Module):
         conv(self.upconv2.packed(), ws["iconv3"], h4, w4, nf // 8, y2d=c2[:, :nf // 8], up=2, e2=P["bn2"])
         conv("conv2", c2, h2, w2, nf // 8, y2d=ws["iconv2"], c_in_real=nf // 8 + f[0] + 1)
         self.reduc2x2.run_nhwc(ws["iconv2"], ws["plane2"], True)
-        depth_2x2_scaled = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        depth_2x2_scaled = out_tensor(2, 1)
         a2 = am()
         ops.lpg_fused_forward(ws["plane2"], B, h2, w2, 2, md, False, depth_2x2_scaled, abs_min=a2)
         self.lpg2x2.abs_min = a2
@@ -478,15 +487,15 @@ class bts(nn.Module):
         c1 = ws["cat1"]
         n16c = nf // 16
         conv(self.upconv1.packed(), ws["iconv2"], h2, w2, n16c, y2d=c1[:, :n16c], up=2)
-        reduc1x1 = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        reduc1x1 = out_tensor(3, 1)
         self.reduc1x1.run_nhwc(c1[:, :n16c], reduc1x1, False)
         ops.pack_planes([reduc1x1, depth_2x2_scaled, depth_4x4_scaled, depth_8x8_scaled], c1[:, n16c:n16c + 4])
-        iconv1 = torch.empty((B, n16c, H, W), dtype=torch.float32, device=dev)
+        iconv1 = out_tensor(5, n16c)
         conv("conv1", c1, H, W, n16c, y_nchw=iconv1)
         fo = None
         if self.params.dataset == 'kitti':
             fo = focal.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
-        final_depth = ops.get_depth_forward(iconv1, P["get_depth"], md, fo)
+        final_depth = ops.get_depth_forward(iconv1, P["get_depth"], md, fo, out=out_tensor(4, 1))
 
         return depth_8x8_scaled, depth_4x4_scaled, depth_2x2_scaled, reduc1x1, final_depth, iconv1
 
@@ -533,18 +542,56 @@ class BtsModel(nn.Module):
         self.encoder = encoder(params)
         self.decoder = bts(params, self.encoder.feat_out_channels, params.bts_size)
         self.native_encoder = True          # set False to force the torch encoder (A/B, debugging)
+        self.sub_batches = 2                # concurrent sub-batches (own HIP stream + workspace each); 1 = off
         self._enc_hip = None
+        self._side_streams = {}
+
+    def _native_ok(self, x):
+        return (self.native_encoder and 'densenet' in self.encoder.params.encoder and not self.training
+                and isinstance(x, torch.Tensor) and x.is_cuda)
+
+    def _forward_native(self, x, focal, slot, outs=None):
+        from .encoder_hip import DenseNetHip
+        if self._enc_hip is None or self._enc_hip.features is not self.encoder.base_model:
+            self._enc_hip = DenseNetHip(self.encoder.base_model)
+        B, _, H, W = x.shape
+        dec = self.decoder
+        ws = dec._workspace(B, H, W, x.device, slot)
+        r = self._enc_hip.run(x.float(), dec.skip_slots(ws), slot=slot)
+        return dec.forward_nhwc(ws, B, H, W, focal, r["dense"], r["norm5"], True, outs=outs)
 
     def forward(self, x, focal):
-        if (self.native_encoder and 'densenet' in self.encoder.params.encoder and not self.training
-                and isinstance(x, torch.Tensor) and x.is_cuda):
-            from .encoder_hip import DenseNetHip
-            if self._enc_hip is None or self._enc_hip.features is not self.encoder.base_model:
-                self._enc_hip = DenseNetHip(self.encoder.base_model)
-            B, _, H, W = x.shape
-            dec = self.decoder
-            ws = dec._workspace(B, H, W, x.device)
-            r = self._enc_hip.run(x.float(), dec.skip_slots(ws))
-            return dec.forward_nhwc(ws, B, H, W, focal, r["dense"], r["norm5"], True)
-        skip_feat = self.encoder(x)
-        return self.decoder(skip_feat, focal)
+        if not self._native_ok(x):
+            skip_feat = self.encoder(x)
+            return self.decoder(skip_feat, focal)
+        B, _, H, W = x.shape
+        S = int(self.sub_batches)
+        if S <= 1 or B % S or B // S < 1:
+            return self._forward_native(x, focal, 0)
+        # Frames are independent in eval mode (bts.py:223-293 has no cross-sample op), so the batch runs as S
+        # concurrent sub-batches, each on its own stream with its own NHWC workspace and writing its slice of
+        # the full-batch outputs: the under-filled launches of one (deep encoder layers, tile-quantisation
+        # tails) overlap the other's kernels.  Per-frame results are bit-identical to the single-stream path.
+        dev = x.device
+        nf16 = self.decoder.num_features // 16
+        full = [torch.empty((B, c, H, W), dtype=torch.float32, device=dev) for c in (1, 1, 1, 1, 1, nf16)]
+        streams = self._side_streams.setdefault(str(dev), [])
+        while len(streams) < S:
+            streams.append(torch.cuda.Stream(dev))
+        cur = torch.cuda.current_stream(dev)
+        b = B // S
+        mins = []
+        focal_d = focal.to(device=dev) if isinstance(focal, torch.Tensor) else focal
+        for i in range(S):
+            st = streams[i]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                lo, hi = i * b, (i + 1) * b
+                self._forward_native(x[lo:hi], focal_d[lo:hi], i, outs=[t[lo:hi] for t in full])
+                dec = self.decoder
+                mins.append(torch.stack([dec.lpg8x8.abs_min, dec.lpg4x4.abs_min, dec.lpg2x2.abs_min]))
+        for i in range(S):
+            cur.wait_stream(streams[i])
+        am = torch.stack(mins).min(dim=0).values                     # abs_min over the whole batch (bts.py:167)
+        self.decoder.lpg8x8.abs_min, self.decoder.lpg4x4.abs_min, self.decoder.lpg2x2.abs_min = am[0], am[1], am[2]
+        return tuple(full)

@@ -84,8 +84,8 @@ class DenseNetHip:
         return P
 
     # ----------------------------------------------------------------------- workspace
-    def _workspace(self, B, H, W, device):
-        key = (B, H, W, str(device))
+    def _workspace(self, B, H, W, device, slot=0):
+        key = (B, H, W, str(device), slot)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
@@ -99,13 +99,13 @@ class DenseNetHip:
             ws["blk%d" % i] = z(n[2 + i], self.c_out[i])
         for i in range(3):
             ws["pool%d" % i] = z(n[3 + i], self.c_out[i])
-        if len(self._ws) >= 4:
+        if len(self._ws) >= 8:
             self._ws.clear()
         self._ws[key] = ws
         return ws
 
     # ----------------------------------------------------------------------------- run
-    def run(self, x: torch.Tensor, skip_dst: Optional[List[Optional[torch.Tensor]]] = None):
+    def run(self, x: torch.Tensor, skip_dst: Optional[List[Optional[torch.Tensor]]] = None, slot: int = 0):
         """x [B,3,H,W] NCHW -> dict(blk3=[npix/32^2, C] NHWC view before norm5, norm5=(scale,shift), taps=...).
 
         ``skip_dst``: four optional [npix_s, C_s] NHWC views (decoder concat slots) receiving the taps
@@ -117,7 +117,7 @@ class DenseNetHip:
             raise ops.BtsHipError("DenseNetHip: expected [B,3,H,W] with H,W multiples of 32")
         dev = x.device
         P = self.packed()
-        ws = self._workspace(B, H, W, dev)
+        ws = self._workspace(B, H, W, dev, slot)
         skip_dst = list(skip_dst) if skip_dst is not None else [None] * 4
         hs = [H // s for s in (2, 4, 8, 16, 32)]
         wss = [W // s for s in (2, 4, 8, 16, 32)]

@@ -386,7 +386,7 @@ def pack_planes(planes: Sequence[torch.Tensor], dst2d: torch.Tensor):
 
 
 def get_depth_forward(iconv1: torch.Tensor, weight: torch.Tensor, max_depth: float,
-                      focal: Optional[torch.Tensor]) -> torch.Tensor:
+                      focal: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """get_depth + scaling (reference bts.py:289-291): iconv1 [B,C,H,W] NCHW -> final_depth [B,1,H,W]."""
     _need(iconv1, "get_depth_forward")
     _need(weight, "get_depth_forward")
@@ -397,7 +397,10 @@ def get_depth_forward(iconv1: torch.Tensor, weight: torch.Tensor, max_depth: flo
         _need(focal, "get_depth_forward")
         if focal.numel() != B or not focal.is_contiguous():
             raise BtsHipError("get_depth_forward: focal must be [B]")
-    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=iconv1.device)
+    if out is None:
+        out = torch.empty((B, 1, H, W), dtype=torch.float32, device=iconv1.device)
+    elif tuple(out.shape) != (B, 1, H, W) or not out.is_contiguous():
+        raise BtsHipError("get_depth_forward: out must be contiguous [B,1,H,W]")
     with torch.cuda.device(iconv1.device):
         rc = _lib.load().bts_get_depth_f32(_ptr(iconv1), _ptr(weight), B, Cc, H, W, float(max_depth), _ptr(focal),
                                            _ptr(out), _stream(iconv1))

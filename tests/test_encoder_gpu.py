@@ -75,6 +75,32 @@ def test_btsmodel_fused_forward_vs_cpu():
     check_outputs(got2, ref_outs, inter, rel_tol=5e-4, what="torch-encoder BtsModel")
 
 
+def test_sub_batch_streams_bit_identical():
+    """BtsModel.sub_batches (concurrent half-batches on two streams, outputs written in place) must not change
+    a single bit, nor the batch-wide abs_min telemetry."""
+    from bts_amd import bts as M
+    params = Params("densenet161_bts", 512, 80.0, "kitti")
+    torch.manual_seed(2)
+    m = M.BtsModel(params).eval().cuda()
+    x = torch.from_numpy(synth.image_batch(4, 64, 96, 9)).cuda()
+    focal = torch.from_numpy(synth.focal_values(4, "kitti", 9)).cuda()
+    with torch.no_grad():
+        m.sub_batches = 1
+        a = [o.clone() for o in m(x, focal)]
+        am_a = [m.decoder.lpg8x8.abs_min.item(), m.decoder.lpg4x4.abs_min.item(), m.decoder.lpg2x2.abs_min.item()]
+        for S in (2, 4):
+            m.sub_batches = S
+            b = m(x, focal)
+            torch.cuda.synchronize()
+            for i in range(6):
+                assert torch.equal(a[i], b[i]), "output %d differs with %d sub-batches" % (i, S)
+            am_b = [m.decoder.lpg8x8.abs_min.item(), m.decoder.lpg4x4.abs_min.item(), m.decoder.lpg2x2.abs_min.item()]
+            assert am_a == am_b
+        m.sub_batches = 3                      # 4 % 3 != 0 -> falls back to one pass
+        c = m(x, focal)
+        assert all(torch.equal(a[i], c[i]) for i in range(6))
+
+
 def test_pooling_kernels():
     from bts_amd import ops
     import torch.nn.functional as F
