@@ -88,7 +88,7 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(params, H, W, seconds_budget=25.0):
+def cpu_baseline(params, H, W, seconds_budget=15.0):
     """The oracle (CPU restatement, oracle/bts_oracle.py) + the same torch encoder on the host cores.
     Bounded sample: B=1 frames of the same 352x1216 workload until ~seconds_budget is spent."""
     from bts_amd import bts as M, synth
@@ -104,7 +104,7 @@ def cpu_baseline(params, H, W, seconds_budget=25.0):
     times = []
     with torch.no_grad():
         t_all = time.perf_counter()
-        for i in range(8):
+        for i in range(40):
             t0 = time.perf_counter()
             feats = enc(img)
             O.decoder_forward(state, feats, focal, params.max_depth, params.dataset)
@@ -249,9 +249,16 @@ def main():
             tr = ops.KernelTrace()
             ops.set_trace(tr)
             nrep = max(3, min(args.steps, 10))
-            model.sub_batches = 1       # kernels timed in isolation (concurrent sub-batches share the chip)
+            # the SAME launches as the timed region (each sub-batch's kernels), but one sub-batch at a time:
+            # concurrent sub-batches share the chip, which would smear per-launch durations
+            model.sub_batches = 1
+            bs = B // S
             for _ in range(nrep):
-                forward()
+                for i in range(S):
+                    if feats_static is not None:
+                        model.decoder([None] + [f[i * bs:(i + 1) * bs] for f in feats_static[1:]], focal[i * bs:(i + 1) * bs])
+                    else:
+                        model(image[i * bs:(i + 1) * bs], focal[i * bs:(i + 1) * bs])
             model.sub_batches = S
             ops.set_trace(None)
             summ = tr.summary()
