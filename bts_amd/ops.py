@@ -18,7 +18,9 @@ ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 
 class KernelTrace:
     """Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
-    Each record: (kernel, tag, algorithmic flops, algorithmic bytes, start event, end event)."""
+    Each record: (kernel, tag, algorithmic flops, algorithmic bytes, start event, end event, executed flops).
+    Algorithmic = the reference formulation's op count; executed = what the kernel's own formulation issues
+    (they differ for the sub-pixel upconv, which needs 4 taps where the reference spends 9)."""
 
     def __init__(self):
         self.records = []
@@ -26,18 +28,20 @@ class KernelTrace:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kern, tag, flops, nbytes, s, e in self.records:
-            d = out.setdefault(kern, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, tags={}))
+        for kern, tag, flops, nbytes, s, e, xflops in self.records:
+            d = out.setdefault(kern, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, xflops=0.0, tags={}))
             ms = s.elapsed_time(e)
             d["launches"] += 1
             d["ms"] += ms
             d["flops"] += flops
             d["bytes"] += nbytes
-            t = d["tags"].setdefault(tag, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["xflops"] += xflops
+            t = d["tags"].setdefault(tag, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, xflops=0.0))
             t["launches"] += 1
             t["ms"] += ms
             t["flops"] += flops
             t["bytes"] += nbytes
+            t["xflops"] += xflops
         return out
 
 
@@ -49,14 +53,14 @@ def set_trace(t: Optional[KernelTrace]):
     _trace = t
 
 
-def _launch(kern: str, tag: str, flops: float, nbytes: float, fn):
+def _launch(kern: str, tag: str, flops: float, nbytes: float, fn, xflops: Optional[float] = None):
     if _trace is None:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     rc = fn()
     e.record()
-    _trace.records.append((kern, tag, flops, nbytes, s, e))
+    _trace.records.append((kern, tag, flops, nbytes, s, e, flops if xflops is None else xflops))
     return rc
 
 
@@ -361,7 +365,8 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         _lib.load().bts_conv_plan_f32(C.byref(d), C.byref(bm), C.byref(bn))
         variant = "conv_fwd_kernel<%d,%d,%s>" % (bm.value, bn.value, "nchw" if y_nchw is not None else "nhwc")
     with torch.cuda.device(x2d.device):
-        rc = _launch(variant, tag, flops, nbytes, lambda: _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d)))
+        rc = _launch(variant, tag, flops, nbytes, lambda: _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d)),
+                     xflops=2.0 * npix_out * c_out * cin * taps)
     _lib.check(rc, "bts_conv_fwd_f32")
     return out
 
