@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbts_hip.so")
 
 SYMBOLS = (
-    "bts_hip_abi_version", "bts_hip_error_string", "bts_lpg_fwd_f32", "bts_lpg_fused_fwd_f32",
+    "bts_hip_abi_version", "bts_hip_error_string", "bts_lpg_fwd_f32", "bts_lpg_bwd_f32", "bts_lpg_fused_fwd_f32",
     "bts_reduc_fwd_f32", "bts_conv_fwd_f32", "bts_nchw_to_nhwc_f32", "bts_nhwc_to_nchw_f32",
     "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32", "bts_maxpool3x3s2_nhwc_f32", "bts_bn_relu_avgpool2_nhwc_f32",
 )
@@ -62,6 +62,8 @@ def load():
     lib.bts_hip_error_string.argtypes = [i]
     lib.bts_lpg_fwd_f32.restype = i
     lib.bts_lpg_fwd_f32.argtypes = [vp, i, i, i, i, vp, vp, vp]
+    lib.bts_lpg_bwd_f32.restype = i
+    lib.bts_lpg_bwd_f32.argtypes = [vp, vp, i, i, i, i, vp, vp]
     lib.bts_lpg_fused_fwd_f32.restype = i
     lib.bts_lpg_fused_fwd_f32.argtypes = [vp, i, i, i, i, i, f, vp, vp, i, l, vp, vp]
     lib.bts_reduc_fwd_f32.restype = i

@@ -258,7 +258,10 @@ class local_planar_guidance(nn.Module):
 
     def forward(self, plane_eq, focal):
         am = torch.empty((), dtype=torch.float32, device=plane_eq.device)
-        depth = ops.lpg_forward(plane_eq, int(self.upratio), abs_min=am)
+        if torch.is_grad_enabled() and plane_eq.requires_grad:
+            depth = ops.LpgFunction.apply(plane_eq, int(self.upratio), am)      # native backward (bts_lpg_bwd_f32)
+        else:
+            depth = ops.lpg_forward(plane_eq, int(self.upratio), abs_min=am)
         self.abs_min = am
         return depth
 

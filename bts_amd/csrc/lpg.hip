@@ -153,6 +153,68 @@ int launch_lpg(const float* plane, int B, int h, int w, int k, int normalize, fl
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ backward
+// One thread per low-resolution cell accumulates the k*k output gradients it produced (no atomics, the
+// mapping of the reference's LocalPlanarGuidanceGradFunctor, local_planar_guidance.cu:95-150).  The derivative
+// is the TRUE one of bts.py:149-173 (what autograd gives): d/dn4 = 1/den_c, d/dn{1,2,3} = -n4*{u,v,1}/den^2 on
+// un-clamped pixels and 0 where the +-1e-3 clamp replaced den by a constant -- the TF op's gradient omits the
+// n4 factor (cu:143-145) and has no clamp.
+template <int K>
+__global__ __launch_bounds__(256) void lpg_bwd_kernel(const float* __restrict__ plane, const float* __restrict__ gout,
+                                                      int B, int h, int w, float* __restrict__ gplane) {
+    const long ncell = (long)B * h * w;
+    const int W = w * K, H = h * K;
+    const long hw = (long)h * w;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ncell; t += (long)gridDim.x * blockDim.x) {
+        const int cx = (int)(t % w);
+        const long r = t / w;
+        const int cy = (int)(r % h);
+        const int b = (int)(r / h);
+        const float* p = plane + ((long)b * 4) * hw + (long)cy * w + cx;
+        const float n1 = p[0], n2 = p[hw], n3 = p[2 * hw], n4 = p[3 * hw];
+        float g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy) {
+            const float v = ((float)dy - (float)(K - 1) * 0.5f) / (float)K;
+            const float* grow = gout + ((long)b * H + cy * K + dy) * W + (long)cx * K;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                const float u = ((float)dx - (float)(K - 1) * 0.5f) / (float)K;
+                const float g = grow[dx];
+                const float den = lpg_den(n1, n2, n3, u, v);
+                const float dc = lpg_clamp(den);
+                const bool clamped = dc != den;
+                g4 += g / dc;
+                const float gd = clamped ? 0.f : -g * n4 / (den * den);     // d(n4/den)/d(den)
+                g1 += gd * u; g2 += gd * v; g3 += gd;
+            }
+        }
+        float* q = gplane + ((long)b * 4) * hw + (long)cy * w + cx;
+        q[0] = g1; q[hw] = g2; q[2 * hw] = g3; q[3 * hw] = g4;
+    }
+}
+
+}  // namespace
+
+extern "C" int bts_lpg_bwd_f32(const float* plane_eq, const float* grad_depth, int B, int h, int w, int upratio,
+                               float* grad_plane_eq, bts_stream_t stream) {
+    if (!plane_eq || !grad_depth || !grad_plane_eq || B <= 0 || h <= 0 || w <= 0) return BTS_ERR_INVALID;
+    const long ncell = (long)B * h * w;
+    long blocks = (ncell + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)blocks), block(256);
+    switch (upratio) {
+        case 1: hipLaunchKernelGGL(lpg_bwd_kernel<1>, grid, block, 0, s, plane_eq, grad_depth, B, h, w, grad_plane_eq); break;
+        case 2: hipLaunchKernelGGL(lpg_bwd_kernel<2>, grid, block, 0, s, plane_eq, grad_depth, B, h, w, grad_plane_eq); break;
+        case 4: hipLaunchKernelGGL(lpg_bwd_kernel<4>, grid, block, 0, s, plane_eq, grad_depth, B, h, w, grad_plane_eq); break;
+        case 8: hipLaunchKernelGGL(lpg_bwd_kernel<8>, grid, block, 0, s, plane_eq, grad_depth, B, h, w, grad_plane_eq); break;
+        default: return BTS_ERR_UNSUPPORTED;
+    }
+    return (int)hipGetLastError();
+}
+
+namespace {
 }  // namespace
 
 extern "C" int bts_lpg_fwd_f32(const float* plane_eq, int B, int h, int w, int upratio, float* depth,

@@ -103,6 +103,39 @@ def lpg_forward(plane_eq: torch.Tensor, upratio: int, abs_min: Optional[torch.Te
     return out
 
 
+def lpg_backward(plane_eq: torch.Tensor, grad_depth: torch.Tensor, upratio: int) -> torch.Tensor:
+    """Gradient of local_planar_guidance.forward w.r.t. plane_eq (what autograd through bts.py:149-173 yields)."""
+    _need(plane_eq, "lpg_backward")
+    _need(grad_depth, "lpg_backward")
+    plane_eq = plane_eq.contiguous()
+    grad_depth = grad_depth.contiguous()
+    B, _, h, w = plane_eq.shape
+    k = int(upratio)
+    if tuple(grad_depth.shape) != (B, h * k, w * k):
+        raise BtsHipError("lpg_backward: grad_depth must be [B,h*k,w*k]")
+    g = torch.empty_like(plane_eq)
+    with torch.cuda.device(plane_eq.device):
+        rc = _lib.load().bts_lpg_bwd_f32(_ptr(plane_eq), _ptr(grad_depth), B, h, w, k, _ptr(g), _stream(plane_eq))
+    _lib.check(rc, "bts_lpg_bwd_f32")
+    return g
+
+
+class LpgFunction(torch.autograd.Function):
+    """autograd shell over the two native LPG kernels (the reference pairs LocalPlanarGuidance with a registered
+    LocalPlanarGuidanceGrad, tensorflow/custom_layer/_local_planar_guidance_grad.py:22-33)."""
+
+    @staticmethod
+    def forward(ctx, plane_eq, upratio, abs_min):
+        ctx.save_for_backward(plane_eq)
+        ctx.upratio = int(upratio)
+        return lpg_forward(plane_eq.detach(), upratio, abs_min=abs_min)
+
+    @staticmethod
+    def backward(ctx, grad_depth):
+        (plane_eq,) = ctx.saved_tensors
+        return lpg_backward(plane_eq, grad_depth, ctx.upratio), None, None
+
+
 def lpg_fused_forward(plane4: torch.Tensor, B: int, h: int, w: int, upratio: int, max_depth: float,
                       normalize: bool, depth_scaled: torch.Tensor, ds_out: Optional[torch.Tensor] = None,
                       ds_factor: int = 1, ds_pix_stride: int = 1, abs_min: Optional[torch.Tensor] = None):

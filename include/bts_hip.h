@@ -46,6 +46,16 @@ const char* bts_hip_error_string(int code);
 int bts_lpg_fwd_f32(const float* plane_eq, int B, int h, int w, int upratio,
                     float* depth, float* abs_min, bts_stream_t stream);
 
+/* Local planar guidance, backward (training callers).
+ * Replaces autograd through local_planar_guidance.forward (pytorch/bts.py:149-173); native statement:
+ * LocalPlanarGuidanceGradKernel<GPUDevice> (tensorflow/custom_layer/local_planar_guidance.cu:95-150, same
+ * one-thread-per-input-cell mapping and argument order: depth_grad, input -> grad_input).
+ *   grad_depth [B,h*k,w*k] -> grad_plane_eq [B,4,h,w].  True derivative of the PyTorch module: includes the n4
+ *   factor the TF op drops (cu:143-145) and zeroes d/dn1..n3 where the +-1e-3 clamp is active (bts.py:168-171).
+ */
+int bts_lpg_bwd_f32(const float* plane_eq, const float* grad_depth, int B, int h, int w, int upratio,
+                    float* grad_plane_eq, bts_stream_t stream);
+
 /* Fused LPG + glue, as bts.forward uses it (pytorch/bts.py:250-256, 264-270, 278-283):
  *   plane4   : [B*h*w,4] cell-interleaved (n1,n2,n3,n4) -- what bts_reduc_fwd_f32 emits
  *   normalize: !=0 -> n[0:3] /= max(||n||_2, 1e-12)  (F.normalize, bts.py:251); 0 if already done

@@ -83,6 +83,34 @@ def test_lpg_random_bitexact(ops, k, shape):
         assert ((np.abs(den) < 1e-3) & (den != 0)).sum() > 0, "test must hit the clamp branch"
 
 
+@pytest.mark.parametrize("k,shape", [(8, (2, 5, 7)), (4, (1, 9, 6)), (2, (3, 4, 10)), (1, (1, 3, 3))])
+def test_lpg_backward_vs_autograd(ops, k, shape):
+    """bts_lpg_bwd_f32 == autograd through the reference expression (oracle), incl. pixels on the +-1e-3 clamp
+    (zero gradient to the normal there) -- through the module's autograd Function."""
+    from bts_amd import bts as M
+    B, h, w = shape
+    rng = np.random.Generator(np.random.PCG64(70 + k))
+    x = rng.standard_normal(size=(B, 4, h, w)).astype(np.float32)
+    x[:, 2] = np.abs(x[:, 2]) * 0.3 + 0.05
+    x[0, 0, 0, 0], x[0, 1, 0, 0], x[0, 2, 0, 0] = 0.0, 0.0, 5e-4          # a clamped cell
+    g = rng.standard_normal(size=(B, h * k, w * k)).astype(np.float32)
+    xc = torch.from_numpy(x).requires_grad_(True)
+    yc, _ = O.lpg_forward(xc, k)
+    den = O.lpg_denominator(torch.from_numpy(x), k)
+    assert (den.abs() > 1e-6).all(), "keep the test away from exact zeros (inf gradients)"
+    yc.backward(torch.from_numpy(g))
+    xg = torch.from_numpy(x).cuda().requires_grad_(True)
+    m = M.local_planar_guidance(k)
+    yg = m(xg, None)
+    assert np.array_equal(yg.detach().cpu().numpy(), yc.detach().numpy())
+    yg.backward(torch.from_numpy(g).cuda())
+    ref, got = xc.grad.numpy(), xg.grad.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 2e-5 * scale + 1e-6, np.abs(got - ref).max()
+    assert np.array_equal(got[0, :3, 0, 0], np.zeros(3, np.float32))       # clamp => no gradient to the normal
+    assert got[0, 3, 0, 0] != 0
+
+
 def test_lpg_rejects_bad_upratio(ops):
     x = torch.zeros(1, 4, 4, 4, device="cuda")
     with pytest.raises(RuntimeError):
