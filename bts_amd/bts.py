@@ -394,11 +394,22 @@ class bts(nn.Module):
     def forward(self, features, focal):
         """bts.forward(features, focal), bts.py:223-293: NCHW encoder taps in, the reference's 6-tuple out."""
         _require_eval(self, "bts")
+        if len(features) != 6:
+            raise BtsHipError("bts.forward: expected the encoder's 6-element tap list, got %d" % len(features))
         skip0, skip1, skip2, skip3, dense = features[1], features[2], features[3], features[4], features[5]
         ops._need(dense, "bts.forward")
         B = dense.shape[0]
         H, W = dense.shape[2] * 32, dense.shape[3] * 32
         f = self.feat_out_channels
+        # host-side shape contract: kernels index these buffers with the sizes derived here
+        for i, (t, s) in enumerate(zip((skip0, skip1, skip2, skip3, dense), (2, 4, 8, 16, 32))):
+            ops._need(t, "bts.forward")
+            want = (B, f[i], H // s, W // s)
+            if tuple(t.shape) != want:
+                raise BtsHipError("bts.forward: features[%d] has shape %s, expected %s (H, W multiples of 32; "
+                                  "channels %s as in bts.py:300-323)" % (i + 1, tuple(t.shape), want, f))
+        if focal is not None and self.params.dataset == 'kitti' and focal.numel() != B:
+            raise BtsHipError("bts.forward: focal must have one entry per frame (%d), got %d" % (B, focal.numel()))
         ws = self._workspace(B, H, W, dense.device)
         # boundary: NCHW encoder taps -> NHWC channel slices (dense_features = ReLU(features[5]), bts.py:225)
         ops.nchw_to_nhwc(dense, ws["f5"][:, :f[4]], relu=True)

@@ -90,6 +90,36 @@ def test_decoder_rejects_cpu_and_train(decoders):
         dec.eval()
 
 
+def test_decoder_validates_tap_shapes(decoders):
+    """Mismatched encoder taps are refused on the host (no kernel ever sees inconsistent sizes)."""
+    from bts_amd._lib import BtsHipError
+    dec = decoders["K"]
+    feats, focal = make_inputs("K", 1, 64, 96, 3)
+    g = [None] + [f.cuda() for f in feats[1:]]
+    bad = list(g)
+    bad[3] = g[3][:, :, :-1]                                   # wrong height at H/8
+    with pytest.raises(BtsHipError):
+        dec(bad, focal.cuda())
+    bad = list(g)
+    bad[2] = g[2][:, :-1]                                      # wrong channel count
+    with pytest.raises(BtsHipError):
+        dec(bad, focal.cuda())
+    with pytest.raises(BtsHipError):
+        dec(g[:5], focal.cuda())                               # short list
+    with pytest.raises(BtsHipError):
+        dec(g, torch.ones(3, device="cuda"))                   # focal per frame
+    out = dec(g, focal.cuda())                                 # and the good call still works afterwards
+    assert out[4].shape == (1, 1, 64, 96)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 32, 32), (3, 32, 96), (5, 96, 32)])
+def test_decoder_odd_batches_and_minimum_sizes(decoders, B, H, W):
+    """Smallest legal image (one 1/32-resolution pixel), odd batch sizes, non-square maps: every tile is ragged."""
+    ref_outs, inter = oracle_run("K", B, H, W, 90 + B)
+    got = hip_run(decoders["K"], "K", B, H, W, 90 + B)
+    check_outputs(got, ref_outs, inter, what="K %dx%dx%d" % (B, H, W))
+
+
 def test_module_level_forwards(decoders):
     """The reference's per-module forwards (NCHW in/out) also run on HIP."""
     from oracle import bts_oracle as O
