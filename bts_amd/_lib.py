@@ -32,6 +32,7 @@ class ConvDesc(C.Structure):
         ("e2_scale", C.c_void_p), ("e2_shift", C.c_void_p),
         ("y", C.c_void_p), ("y_pix_stride", C.c_long), ("y_nchw", C.c_int),
         ("subpixel", C.c_int), ("y2", C.c_void_p), ("y2_pix_stride", C.c_long),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_long),
     ]
 
 

@@ -378,6 +378,8 @@ class bts(nn.Module):
             iconv2=z(n2, nf // 8),
             plane2=z(n2, 4),
             cat1=z(n1, nf // 16 + 4),                            # [upconv1 | reduc1x1 d2 d4 d8]
+            # scratch for split-K of under-filled launches (bts_conv_desc.splitk_ws): 8 splits x [n16, nf]
+            splitk=torch.empty(8 * n16 * nf, dtype=torch.float32, device=device),
         )
         if len(self._bufs) >= 8:
             self._bufs.clear()
@@ -435,7 +437,7 @@ class bts(nn.Module):
             wp = P[name_w] if isinstance(name_w, str) else name_w
             return ops.conv_forward(x2d, B, hh, ww, wp[0], cout, 3, dil=1, up=up, act=ELU, e2=e2, pre=pre, pre_relu=pre_relu,
                                     y2d=y2d, y_nchw=y_nchw, tag="decoder_upconv" if up == 2 else "decoder_conv",
-                                    c_in_real=c_in_real, subpixel=(up == 2))
+                                    c_in_real=c_in_real, subpixel=(up == 2), splitk_ws=ws["splitk"])
 
         # H/16 and H/8 trunk (bts.py:226-235)
         conv(self.upconv5.packed(), dense2d, H // 32, W // 32, nf, y2d=ws["cat5"][:, :nf], up=2, e2=P["bn5"],

@@ -49,6 +49,10 @@ struct ConvArgs {
     long M;                          // B*H*W
     int n_ntiles;
     int tiles_per_class;
+    // split-K (under-filled launches): split s of `ksplit` covers K-steps [s*its_per_split, ...) and stores raw
+    // fp32 partial sums to ws[s][m][n] (row length ws_ld); splitk_reduce_kernel sums them and applies the epilogue
+    int ksplit, its_per_split, ws_ld;
+    float* ws;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -181,8 +185,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
     // sub-pixel upconv: the grid covers 4 parity classes (py,px) of output pixels, each its own GEMM over the
     // SOURCE pixels with a 2x2 kernel (weights pre-summed per class) -- see bts_conv_desc.subpixel
-    const int cls = swz / a.tiles_per_class;
-    const int tcl = swz - cls * a.tiles_per_class;
+    const int tiles_all = a.tiles_per_class * (a.subpix ? 4 : 1);
+    const int split = swz / tiles_all;
+    const int srem = swz - split * tiles_all;
+    const int cls = srem / a.tiles_per_class;
+    const int tcl = srem - cls * a.tiles_per_class;
     const int mt_idx = tcl / a.n_ntiles, nt_idx = tcl % a.n_ntiles;
     const long m0 = (long)mt_idx * BM;
     const int n0 = nt_idx * BN;
@@ -235,7 +242,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
         wrow[p] = (unsigned)n * (unsigned)a.k_pad + (unsigned)lk;
     }
 
-    const int nit = a.k_pad / BK;
+    const int it0 = split * a.its_per_split;                       // this workgroup's K-step range
+    const int nit = min(a.k_pad / BK - it0, a.its_per_split);
 
     f32x4 ra[PA], rb[PB];
     f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
@@ -258,13 +266,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     // Prefetch distance 2 with ONE staging register set: during step `it` the registers hold tile it+1 (its loads
     // were issued a full step ago, so they have landed even on an HBM miss): write it to the other LDS buffer,
     // then reuse the registers for the loads of tile it+2, which get a whole step of MFMAs to arrive.
-    int tap = 0, kc = 0;                          // lean path: (tap, channel chunk) of the K-step being loaded
-    auto issue = [&](int t) {
+    int tap = fastk ? it0 / kchunks : 0;          // lean path: (tap, channel chunk) of the K-step being loaded
+    int kc = fastk ? it0 - tap * kchunks : 0;
+    auto issue = [&](int t) {                     // t = local step index; global K-step = it0 + t
         if (fastk) {
             if (t > 0 && ++kc == kchunks) { kc = 0; ++tap; }
-            issue_loads_fast<PA, PB>(a, wbase, pad_y, pad_x, t, tap, kc, fbase, vmask, wrow, ra, rb, ps, pb, okmask, lk);
+            issue_loads_fast<PA, PB>(a, wbase, pad_y, pad_x, it0 + t, tap, kc, fbase, vmask, wrow, ra, rb, ps, pb, okmask, lk);
         } else {
-            issue_loads<PA, PB>(a, wbase, pad_y, pad_x, t, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
+            issue_loads<PA, PB>(a, wbase, pad_y, pad_x, it0 + t, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
         }
     };
     issue(0);
@@ -318,6 +327,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
 
     // ---------------------------------------------------------------- epilogue
     // D register r of lane (li, lh) is D[row][col = li] with row = (r&3) + 8*(r>>2) + 4*lh (MF 32) or 4*lh + r (MF 16)
+    if (a.ksplit > 1) {                                  // partial sums only: ws[split][m][n]
+        float* __restrict__ wsp = a.ws + (size_t)split * a.M * a.ws_ld;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) {
+                    const int drow = MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * lh : 4 * lh + r;
+                    const long m = m0 + (wm * TM + i) * MF + (NCHW_OUT ? li : drow);
+                    const int n = n0 + (wn * TN + j) * MF + (NCHW_OUT ? drow : li);
+                    if (m < a.M && n < a.c_out) wsp[m * a.ws_ld + n] = acc[i][j][r];
+                }
+        return;
+    }
     const bool has_e1 = a.e1_scale != nullptr, has_e2 = a.e2_scale != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -369,13 +393,58 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
         }
 }
 
+// Second pass of a split-K convolution: out = E(sum_s ws[s][m][n]) in a FIXED order (deterministic), then the
+// same epilogue / destinations as the fused path.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, int nchw) {
+    const long total = a.M * (long)a.c_out;
+    const long HW = (long)a.H * a.W;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long m = t / a.c_out;
+        const int n = (int)(t - m * a.c_out);
+        float v = 0.f;
+        for (int sidx = 0; sidx < a.ksplit; ++sidx) v += a.ws[((size_t)sidx * a.M + m) * a.ws_ld + n];
+        if (a.e1_scale) v = v * a.e1_scale[n] + a.e1_shift[n];
+        v = apply_act(v, a.act);
+        if (a.e2_scale) v = v * a.e2_scale[n] + a.e2_shift[n];
+        if (nchw) {
+            const long b = m / HW, yx = m % HW;
+            a.y[(b * a.c_out + n) * HW + yx] = v;
+        } else {
+            a.y[m * a.y_pix_stride + n] = v;
+            if (a.y2) a.y2[m * a.y2_pix_stride + n] = v;
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int MF = 32>
-int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s) {
+int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     ConvArgs a = a0;
     const long n_mtiles = (a.M + BM - 1) / BM;
     a.n_ntiles = (a.c_out + BN - 1) / BN;            // tiles over REAL channels; wrow clamps into c_out_pad
     a.tiles_per_class = (int)(n_mtiles * a.n_ntiles);
-    const long nwg = n_mtiles * a.n_ntiles * (a.subpix ? 4 : 1);
+    const long tiles = n_mtiles * a.n_ntiles * (a.subpix ? 4 : 1);
+    // split-K when the grid would leave most of the 256 CUs idle (M-starved deep encoder layers) and the caller
+    // lent a workspace.  The split factor is a function of the PER-FRAME geometry only (H*W, c_out, K) -- sized for
+    // the nominal 8-frame sub-batch -- never of the batch size: an output element's summation order, hence its
+    // bits, must not depend on how many frames share the launch (frames are independent, bts.py:223-293).
+    const int nit_all = a.k_pad / BK;
+    a.ksplit = 1; a.its_per_split = nit_all; a.ws_ld = (a.c_out + 3) & ~3;
+    static const int split_max = getenv("BTS_CONV_SPLITK") ? atoi(getenv("BTS_CONV_SPLITK")) : 8;
+    static const long split_below = getenv("BTS_CONV_SPLITK_BELOW") ? atol(getenv("BTS_CONV_SPLITK_BELOW")) : 1000;
+    if (!a.subpix && a.ws != nullptr && split_max > 1) {
+        const long tiles64 = ((8L * a.H * a.W + 63) / 64) * a.n_ntiles;     // 64-row tiles of a nominal 8-frame launch
+        if (tiles64 < split_below) {
+            static const long split_target = getenv("BTS_CONV_SPLITK_TARGET") ? atol(getenv("BTS_CONV_SPLITK_TARGET")) : 2048;
+            long sp = split_target / tiles64;
+            if (sp > split_max) sp = split_max;
+            if (sp > nit_all / 4) sp = nit_all / 4;
+            if (sp > 1 && sp * a.M * a.ws_ld <= ws_floats) {
+                a.its_per_split = (nit_all + (int)sp - 1) / (int)sp;
+                a.ksplit = (nit_all + a.its_per_split - 1) / a.its_per_split;     // no empty splits
+            }
+        }
+    }
+    const long nwg = tiles * a.ksplit;
     if (nwg > 0x7fffffffL) return BTS_ERR_INVALID;
     size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     if (const char* f = getenv("BTS_CONV_LDS_KB")) {   // tuning aid: inflate LDS to limit workgroups per CU
@@ -397,6 +466,12 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s) {
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, a);
+    }
+    if (a.ksplit > 1) {
+        const long total = a.M * (long)a.c_out;
+        long blocks = (total + 255) / 256;
+        if (blocks > 256L * 8) blocks = 256L * 8;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, nchw ? 1 : 0);
     }
     return (int)hipGetLastError();
 }
@@ -476,19 +551,23 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if (a.H <= 0 || a.W <= 0) return BTS_ERR_INVALID;
     a.M = (long)d->B * a.H * a.W;
     a.n_ntiles = 0; a.tiles_per_class = 0;
+    a.ksplit = 1; a.its_per_split = 0; a.ws_ld = 0;
+    a.ws = d->splitk_ws;
+    const long wsf = d->splitk_ws ? d->splitk_ws_floats : 0;
+    if (d->splitk_ws && (((uintptr_t)d->splitk_ws & 15) || d->splitk_ws_floats < 0)) return BTS_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const bool nchw = d->y_nchw != 0;
     int bm, bn;
     choose_tile(a.M * (a.subpix ? 4 : 1), d->c_out, &bm, &bn);
-    if (bn == 48) return bm == 128 ? launch_conv<128, 48, 4, 1, 16>(a, nchw, s) : launch_conv<64, 48, 4, 1, 16>(a, nchw, s);
+    if (bn == 48) return bm == 128 ? launch_conv<128, 48, 4, 1, 16>(a, nchw, s, wsf) : launch_conv<64, 48, 4, 1, 16>(a, nchw, s, wsf);
     static const int w8 = getenv("BTS_CONV_W8") ? atoi(getenv("BTS_CONV_W8")) : 0;
     if (w8) {
-        if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4>(a, nchw, s) : launch_conv<64, 128, 2, 2>(a, nchw, s);
-        if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2>(a, nchw, s) : launch_conv<64, 64, 2, 2>(a, nchw, s);
+        if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 2>(a, nchw, s, wsf);
+        if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2>(a, nchw, s, wsf);
     }
-    if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 2>(a, nchw, s) : launch_conv<64, 128, 2, 2>(a, nchw, s);
-    if (bn == 64) return bm == 128 ? launch_conv<128, 64, 2, 2>(a, nchw, s) : launch_conv<64, 64, 2, 2>(a, nchw, s);
-    return launch_conv<128, 32, 4, 1>(a, nchw, s);
+    if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 2>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 2>(a, nchw, s, wsf);
+    if (bn == 64) return bm == 128 ? launch_conv<128, 64, 2, 2>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2>(a, nchw, s, wsf);
+    return launch_conv<128, 32, 4, 1>(a, nchw, s, wsf);
 }
 
 extern "C" int bts_conv_plan_f32(const bts_conv_desc* d, int* bm, int* bn) {

@@ -95,6 +95,8 @@ class DenseNetHip:
             return torch.zeros((npix, c), dtype=torch.float32, device=device)
 
         ws = dict(img=z(n[0], 4), mid=z(n[2], self.c_mid))
+        # scratch for split-K of the M-starved deep layers (see bts_conv_desc.splitk_ws): 8 splits x [n/16^2, 512]
+        ws["splitk"] = torch.empty(8 * n[4] * 512, dtype=torch.float32, device=device)
         for i in range(4):
             ws["blk%d" % i] = z(n[2 + i], self.c_out[i])
         for i in range(3):
@@ -140,16 +142,16 @@ class DenseNetHip:
             for li, L in enumerate(layers):
                 cin = L["cin"]
                 ops.conv_forward(buf[:, :cin], B, h, w, L["w1"], self.c_mid, 1, pre=L["pre"], pre_relu=True, e1=L["e1"],
-                                 act=RELU, y2d=mid, tag="enc_b%d_1x1" % (bi + 1))
+                                 act=RELU, y2d=mid, tag="enc_b%d_1x1" % (bi + 1), splitk_ws=ws["splitk"])
                 ops.conv_forward(mid, B, h, w, L["w2"], self.growth, 3, y2d=buf[:, cin:cin + self.growth],
-                                 tag="enc_b%d_3x3" % (bi + 1))
+                                 tag="enc_b%d_3x3" % (bi + 1), splitk_ws=ws["splitk"])
             if bi < 3:
                 T = P["trans"][bi]
                 pooled = ws["pool%d" % bi]
                 ops.bn_relu_avgpool2(buf, B, h, w, T["scale"], T["shift"], pooled)
                 nxt = ws["blk%d" % (bi + 1)]
                 ops.conv_forward(pooled, B, h // 2, w // 2, T["w"], T["c_out"], 1, y2d=nxt[:, :T["c_out"]],
-                                 y2_2d=skip_dst[bi + 2] if bi < 2 else None, tag="enc_trans")
+                                 y2_2d=skip_dst[bi + 2] if bi < 2 else None, tag="enc_trans", splitk_ws=ws["splitk"])
         return dict(dense=ws["blk3"], norm5=P["norm5"], skips=skip_dst, B=B, H=H, W=W)
 
     def taps_nchw(self, x: torch.Tensor) -> List[torch.Tensor]:

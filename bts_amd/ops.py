@@ -323,7 +323,8 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
                  e2: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                  y2d: Optional[torch.Tensor] = None, y_nchw: Optional[torch.Tensor] = None,
                  tag: str = "conv", c_in_real: Optional[int] = None, stride: int = 1, pad: Optional[int] = None,
-                 y2_2d: Optional[torch.Tensor] = None, subpixel: bool = False):
+                 y2_2d: Optional[torch.Tensor] = None, subpixel: bool = False,
+                 splitk_ws: Optional[torch.Tensor] = None):
     """One fused convolution (see bts_conv_desc in include/bts_hip.h).
     ``subpixel``: w_packed comes from pack_upconv_subpixel; computes nearest-2x + conv3x3 (pass ksize=3, up=2).
 
@@ -388,6 +389,11 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
             raise BtsHipError("conv_forward: y_nchw must be contiguous [B,c_out,H,W]")
         d.y, d.y_pix_stride, d.y_nchw = y_nchw.data_ptr(), 0, 1
         out = y_nchw
+    if splitk_ws is not None:
+        _need(splitk_ws, "conv_forward")
+        if not splitk_ws.is_contiguous():
+            raise BtsHipError("conv_forward: splitk_ws must be contiguous")
+        d.splitk_ws, d.splitk_ws_floats = splitk_ws.data_ptr(), splitk_ws.numel()
     cin = c_in_real if c_in_real is not None else c_in_ld
     npix_out = B * H * W
     flops = 2.0 * npix_out * c_out * cin * flops_taps      # algorithmic: the reference's 3x3 on the upsampled map

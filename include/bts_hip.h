@@ -134,6 +134,10 @@ typedef struct bts_conv_desc {
     float* y2;               /* optional second NHWC destination of the same result (a skip tensor
                                 that must live in two concat buffers), or NULL                      */
     long  y2_pix_stride;
+    float* splitk_ws;        /* optional scratch (caller-owned, exclusive to this stream while the call runs) that
+                                lets under-filled launches split K over several workgroups: partial sums go here
+                                and a second kernel reduces them in a fixed order (deterministic); NULL = never split */
+    long  splitk_ws_floats;  /* its size in floats (8 * M * round_up(c_out,4) is always enough)                     */
 } bts_conv_desc;
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);

@@ -350,6 +350,48 @@ def test_conv_growth48_mfma16(ops, shape, nchw):
     close(y, ref, rtol=1e-4, atol=2e-5, what="growth-48 conv")
 
 
+@pytest.mark.parametrize("cin,cout,k,shape,nchw", [(1056, 192, 1, (1, 11, 38), False), (192, 48, 3, (2, 11, 19), False),
+                                                    (448, 256, 3, (1, 6, 9), True), (2112, 1056, 1, (1, 5, 7), False)])
+def test_conv_split_k(ops, cin, cout, k, shape, nchw):
+    """Under-filled launches (few output tiles, long K) split K over workgroups when a workspace is lent; the
+    result must match the unsplit launch to rounding, be deterministic, and honour prologue/epilogue/2nd output."""
+    B, h, w = shape
+    rng = np.random.Generator(np.random.PCG64(cin + cout + k))
+    x = rng.standard_normal(size=(B, cin, h, w), dtype=np.float32)
+    wt = (rng.standard_normal(size=(cout, cin, k, k)) * 0.02).astype(np.float32)
+    ps = rng.uniform(0.5, 1.5, size=cin).astype(np.float32)
+    pb = (rng.standard_normal(size=cin) * 0.2).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, size=cout).astype(np.float32)
+    sh = (rng.standard_normal(size=cout) * 0.1).astype(np.float32)
+    xt = torch.from_numpy(x)
+    ref = F.conv2d(F.relu(xt * torch.from_numpy(ps).view(1, -1, 1, 1) + torch.from_numpy(pb).view(1, -1, 1, 1)),
+                   torch.from_numpy(wt), padding=k // 2)
+    ref = F.relu(ref * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1))
+    xin = torch.zeros(B * h * w, cin, device="cuda")
+    ops.nchw_to_nhwc(dev(x), xin)
+    wp, cop, cld = ops.pack_conv_weight(dev(wt))
+    pre = (dev(ps), dev(pb))
+    e1 = (dev(ops.pad_vec(torch.from_numpy(sc), cop, 1.0)), dev(ops.pad_vec(torch.from_numpy(sh), cop, 0.0)))
+    wsbuf = torch.empty(8 * B * h * w * ops.round_up(cout, 4), device="cuda")
+    outs = []
+    for ws in (None, wsbuf, wsbuf):
+        if nchw:
+            y = torch.empty(B, cout, h, w, device="cuda")
+            ops.conv_forward(xin, B, h, w, wp, cout, k, pre=pre, pre_relu=True, e1=e1, act=ops.ACT_RELU, y_nchw=y, splitk_ws=ws)
+            outs.append(y)
+        else:
+            yb = torch.zeros(B * h * w, cout + 4, device="cuda")
+            y2 = torch.zeros(B * h * w, cout, device="cuda")
+            ops.conv_forward(xin, B, h, w, wp, cout, k, pre=pre, pre_relu=True, e1=e1, act=ops.ACT_RELU, y2d=yb[:, 4:],
+                             y2_2d=y2, splitk_ws=ws)
+            assert torch.equal(yb[:, 4:], y2) and torch.count_nonzero(yb[:, :4]).item() == 0
+            outs.append(ops.nhwc_to_nchw(y2, B, h, w))
+    scale = max(1.0, float(ref.abs().max()))
+    for y in outs:
+        close(y, ref, rtol=1e-4, atol=2e-5 * scale, what="split-K conv %d->%d" % (cin, cout))
+    assert torch.equal(outs[1], outs[2]), "split-K must be deterministic"
+
+
 def test_conv_k_permutation(ops):
     """pack_conv_weight(perm=...) lets the NHWC buffer keep its own channel order."""
     B, h, w, cin, cout = 1, 6, 8, 48, 32

@@ -29,7 +29,7 @@ def test_cabi_exports_every_declared_symbol():
 
 def test_conv_desc_layout_matches_header():
     from bts_amd._lib import ConvDesc
-    assert ctypes.sizeof(ConvDesc) == 176
+    assert ctypes.sizeof(ConvDesc) == 192
     assert ConvDesc.w.offset == 56 and ConvDesc.y.offset == 136 and ConvDesc.y_nchw.offset == 152
 
 
