@@ -18,12 +18,10 @@ There is no PyTorch/CPU fallback: CPU tensors or a missing libbts_hip.so raise.
 """
 from __future__ import annotations
 
-import math
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as torch_nn_func
 
 from . import ops
 from ._lib import BtsHipError

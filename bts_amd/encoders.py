@@ -11,11 +11,10 @@ The encoder is caller-side of the hot path: it stays on PyTor
 from __future__ import annotations
 
 from collections import OrderedDict
-from typing import List, Sequence
+from typing import Sequence
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 # --------------------------------------------------------------------------- DenseNet
