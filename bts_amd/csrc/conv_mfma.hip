@@ -430,11 +430,11 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     const int nit_all = a.k_pad / BK;
     a.ksplit = 1; a.its_per_split = nit_all; a.ws_ld = (a.c_out + 3) & ~3;
     static const int split_max = getenv("BTS_CONV_SPLITK") ? atoi(getenv("BTS_CONV_SPLITK")) : 8;
-    static const long split_below = getenv("BTS_CONV_SPLITK_BELOW") ? atol(getenv("BTS_CONV_SPLITK_BELOW")) : 1000;
+    static const long split_below = getenv("BTS_CONV_SPLITK_BELOW") ? atol(getenv("BTS_CONV_SPLITK_BELOW")) : 700;
     if (!a.subpix && a.ws != nullptr && split_max > 1) {
         const long tiles64 = ((8L * a.H * a.W + 63) / 64) * a.n_ntiles;     // 64-row tiles of a nominal 8-frame launch
         if (tiles64 < split_below) {
-            static const long split_target = getenv("BTS_CONV_SPLITK_TARGET") ? atol(getenv("BTS_CONV_SPLITK_TARGET")) : 2048;
+            static const long split_target = getenv("BTS_CONV_SPLITK_TARGET") ? atol(getenv("BTS_CONV_SPLITK_TARGET")) : 1024;
             long sp = split_target / tiles64;
             if (sp > split_max) sp = split_max;
             if (sp > nit_all / 4) sp = nit_all / 4;
