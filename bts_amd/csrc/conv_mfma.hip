@@ -560,13 +560,18 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     int bm, bn;
     choose_tile(a.M * (a.subpix ? 4 : 1), d->c_out, &bm, &bn);
     if (bn == 48) return bm == 128 ? launch_conv<128, 48, 4, 1, 16>(a, nchw, s, wsf) : launch_conv<64, 48, 4, 1, 16>(a, nchw, s, wsf);
-    static const int w8 = getenv("BTS_CONV_W8") ? atoi(getenv("BTS_CONV_W8")) : 0;
-    if (w8) {
-        if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 2>(a, nchw, s, wsf);
-        if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2>(a, nchw, s, wsf);
+    // 8-wave workgroups (two waves per SIMD from the same tile) for the 128-row tiles: +2 % end to end over the
+    // 4-wave layout on MI355X (more waves to cover each other's staging); BTS_CONV_W8=0 selects the 4-wave kernels
+    static const int w8 = getenv("BTS_CONV_W8") ? atoi(getenv("BTS_CONV_W8")) : 1;
+    static const int w8s = getenv("BTS_CONV_W8S") ? atoi(getenv("BTS_CONV_W8S")) : 1;
+    if (bn == 128) {
+        if (bm == 128) return w8 ? launch_conv<128, 128, 2, 4>(a, nchw, s, wsf) : launch_conv<128, 128, 2, 2>(a, nchw, s, wsf);
+        return w8s ? launch_conv<64, 128, 2, 4>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 2>(a, nchw, s, wsf);
     }
-    if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 2>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 2>(a, nchw, s, wsf);
-    if (bn == 64) return bm == 128 ? launch_conv<128, 64, 2, 2>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2>(a, nchw, s, wsf);
+    if (bn == 64) {
+        if (bm == 128) return w8 ? launch_conv<128, 64, 4, 2>(a, nchw, s, wsf) : launch_conv<128, 64, 2, 2>(a, nchw, s, wsf);
+        return launch_conv<64, 64, 2, 2>(a, nchw, s, wsf);
+    }
     return launch_conv<128, 32, 4, 1>(a, nchw, s, wsf);
 }
 
