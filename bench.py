@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step all-gather of the 5 depth maps (N>1)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="run the per-GPU batch as this many concurrent sub-batches on separate HIP streams (one graph): "
                          "frames are independent, so under-filled launches of one sub-batch overlap the other's")
     ap.add_argument("--decoder-only", action="store_true", help="time only the decoder hot path on encoder-shaped features")
@@ -161,7 +161,8 @@ def main():
     B, H, W = args.batch, args.height, args.width
     log("building model %s" % args.encoder)
     S = max(1, args.streams)
-    assert B % S == 0, "--batch must be divisible by --streams"
+    while S > 1 and B % S:
+        S -= 1
     model = build_model(params, device, seed=0)
     model.native_encoder = args.encoder_backend == "hip"
     model.sub_batches = S

@@ -96,7 +96,7 @@ def test_sub_batch_streams_bit_identical():
                 assert torch.equal(a[i], b[i]), "output %d differs with %d sub-batches" % (i, S)
             am_b = [m.decoder.lpg8x8.abs_min.item(), m.decoder.lpg4x4.abs_min.item(), m.decoder.lpg2x2.abs_min.item()]
             assert am_a == am_b
-        m.sub_batches = 3                      # 4 % 3 != 0 -> falls back to one pass
+        m.sub_batches = 3                      # 4 % 3 != 0 -> largest divisor below (2)
         c = m(x, focal)
         assert all(torch.equal(a[i], c[i]) for i in range(6))
 
