@@ -250,16 +250,14 @@ def main():
             tr = ops.KernelTrace()
             ops.set_trace(tr)
             nrep = max(3, min(args.steps, 10))
-            # the SAME launches as the timed region (each sub-batch's kernels), but one sub-batch at a time:
-            # concurrent sub-batches share the chip, which would smear per-launch durations
+            # Kernel-quality leg: the forward once more, un-graphed, ONE launch at a time over the full per-GPU batch
+            # (sub_batches = 1), HIP events around every hand-written launch.  The timed region above runs the very
+            # same kernels as S concurrent sub-batches whose launches overlap on the chip, which is what buys the
+            # wall-clock number but makes a per-launch duration there meaningless (rocprofv3 of the default command
+            # shows the overlapped durations; `--streams 1` reproduces these isolated ones, see profiles/README.md).
             model.sub_batches = 1
-            bs = B // S
             for _ in range(nrep):
-                for i in range(S):
-                    if feats_static is not None:
-                        model.decoder([None] + [f[i * bs:(i + 1) * bs] for f in feats_static[1:]], focal[i * bs:(i + 1) * bs])
-                    else:
-                        model(image[i * bs:(i + 1) * bs], focal[i * bs:(i + 1) * bs])
+                forward()
             model.sub_batches = S
             ops.set_trace(None)
             summ = tr.summary()
@@ -270,8 +268,9 @@ def main():
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": pmc_traffic(dom),
                     "executed": round(executed, 2), "executed_frac": round(executed / PEAK_MFMA_F32_TFLOPS, 4),
-                    "note": "achieved = algorithmic FLOP of the reference formulation / HIP-event time of isolated launches; "
-                            "executed = FLOP the kernel's own formulation issues (sub-pixel upconv: 4 taps instead of 9)",
+                    "note": "achieved = algorithmic FLOP of the reference formulation / HIP-event time of isolated full-batch "
+                            "launches (the timed region overlaps %d sub-batches of the same kernels); executed = FLOP the "
+                            "kernel's own formulation issues (sub-pixel upconv: 4 taps instead of 9)" % S,
                     "launches_per_step": d["launches"] // nrep,
                     "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                     "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
