@@ -44,9 +44,11 @@ def lpg_forward(plane_eq: Tensor, upratio: int) -> Tuple[Tensor, Tensor]:
     pe = torch.repeat_interleave(plane_eq, k, 2)
     pe = torch.repeat_interleave(pe, k, 3)
     n1, n2, n3, n4 = pe[:, 0], pe[:, 1], pe[:, 2], pe[:, 3]
-    u = torch.arange(k).reshape(1, 1, k).float().repeat(B, h * k, w)
+    # the reference builds u, v on the CPU and moves them with .cuda() every call (bts.py:157,160); `.to` is
+    # the device-agnostic spelling (a no-op on CPU tensors)
+    u = torch.arange(k).reshape(1, 1, k).float().repeat(B, h * k, w).to(plane_eq.device)
     u = (u - (float(k) - 1) * 0.5) / float(k)
-    v = torch.arange(k).reshape(1, k, 1).float().repeat(B, h, w * k)
+    v = torch.arange(k).reshape(1, k, 1).float().repeat(B, h, w * k).to(plane_eq.device)
     v = (v - (float(k) - 1) * 0.5) / float(k)
     divided = n1 * u + n2 * v + n3
     abs_min = torch.abs(divided).min()
