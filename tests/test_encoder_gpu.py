@@ -1,5 +1,7 @@
 """GPU: the DenseNet encoder on the HIP conv kernel (bts_amd.encoder_hip) against the same nn modules
 run by PyTorch on the CPU, and the fused BtsModel.forward against CPU encoder + oracle decoder."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -99,6 +101,51 @@ def test_sub_batch_streams_bit_identical():
         m.sub_batches = 3                      # 4 % 3 != 0 -> largest divisor below (2)
         c = m(x, focal)
         assert all(torch.equal(a[i], c[i]) for i in range(6))
+
+
+def test_bts_test_py_call_protocol(tmp_path):
+    """The reference inference driver's sequence (bts_test.py:70-76, 90-102, 127-138) against the plugin module:
+    import-by-name from the checkpoint directory, BtsModel(params=args), DataParallel, load_state_dict of a
+    'module.'-prefixed checkpoint, eval, cuda, model(image, focal) -> 6 outputs -> .cpu().numpy().squeeze()."""
+    import importlib
+    import sys
+    ckpt_dir = tmp_path / "bts_eigen_v2_pytorch_densenet161"
+    ckpt_dir.mkdir()
+    (ckpt_dir / "bts_eigen_v2_pytorch_densenet161.py").write_text("from bts_amd.bts import *\n")   # INTEGRATION.md, recipe A
+    args = E_args = __import__("bts_amd.evaltools", fromlist=["x"]).parse_args(
+        ["--encoder", "densenet161_bts", "--dataset", "kitti", "--max_depth", "80", "--input_height", "64", "--input_width", "96",
+         "--model_name", "bts_eigen_v2_pytorch_densenet161", "--checkpoint_path", str(ckpt_dir / "model")])
+    model_dir = os.path.dirname(args.checkpoint_path)
+    sys.path.append(model_dir)
+    ns = {}
+    for key, val in vars(importlib.import_module(args.model_name)).items():
+        if key.startswith('__') and key.endswith('__'):
+            continue
+        ns[key] = val
+    BtsModel = ns["BtsModel"]
+    assert all(k in ns for k in ("encoder", "bts", "atrous_conv", "upconv", "reduction_1x1", "local_planar_guidance",
+                                 "silog_loss", "weights_init_xavier", "bn_init_as_tf"))
+    # a checkpoint as bts_main.py:723-728 writes it (saved from the DataParallel/DDP wrapper)
+    torch.manual_seed(4)
+    src = torch.nn.DataParallel(BtsModel(params=args))
+    torch.save({'global_step': 7, 'model': src.state_dict()}, args.checkpoint_path)
+    model = BtsModel(params=args)
+    model = torch.nn.DataParallel(model)
+    checkpoint = torch.load(args.checkpoint_path, weights_only=True)
+    model.load_state_dict(checkpoint['model'])
+    model.eval()
+    model.cuda()
+    image = torch.from_numpy(synth.image_batch(1, 64, 96, 3))
+    focal = torch.from_numpy(synth.focal_values(1, "kitti", 3))
+    with torch.no_grad():
+        lpg8x8, lpg4x4, lpg2x2, reduc1x1, depth_est, _ = model(image.cuda(), focal.cuda())
+        pred = depth_est.cpu().numpy().squeeze()
+        ref = src.module.eval().cuda()(image.cuda(), focal.cuda())[4].cpu().numpy().squeeze()
+    assert pred.shape == (64, 96) and np.isfinite(pred).all() and (pred > 0).all()
+    assert lpg8x8[0].shape == (1, 64, 96)
+    assert np.array_equal(pred, ref)                          # the checkpoint round trip changes nothing
+    assert model.module.decoder.lpg8x8.abs_min is not None    # bts_main.py:484-486 reads these
+    sys.path.remove(model_dir)
 
 
 def test_pooling_kernels():
