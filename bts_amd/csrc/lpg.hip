@@ -34,24 +34,28 @@ __device__ __forceinline__ float lpg_clamp(float d) {
 }
 
 // block-min of |den| then ONE atomic per block: same-address atomics serialise in L2 (~12 ns each on
-// MI355X), so the grid is also capped at 1024 blocks.  abs(den) >= 0 so the uint order is the float order.
+// MI355X), so blocks are fat (16 waves) and the grid is capped at 512.  abs(den) >= 0 so the uint order is
+// the float order.
+constexpr int LPG_ROWS = 16;                       // block = 64 x 16 threads
 __device__ __forceinline__ void publish_abs_min(float m, unsigned* abs_min_bits) {
-    __shared__ float wave_min[4];
+    __shared__ float wave_min[LPG_ROWS];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     if ((tid & 63) == 0) wave_min[tid >> 6] = m;
     __syncthreads();
-    if (tid == 0) {
-        m = fminf(fminf(wave_min[0], wave_min[1]), fminf(wave_min[2], wave_min[3]));
-        atomicMin(abs_min_bits, __float_as_uint(m));
+    if (tid < 64) {
+        m = tid < LPG_ROWS ? wave_min[tid] : __uint_as_float(0x7f800000u);
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+        if (tid == 0) atomicMin(abs_min_bits, __float_as_uint(m));
     }
 }
 
 // K = upratio (1,2,4,8).  PLANAR: input [B,4,h,w]; else cell-interleaved [B*h*w,4].
 // FUSED: optional normalize, divide by max_depth, strided nearest-downsample side output.
 template <int K, int V, bool PLANAR, bool FUSED>
-__global__ __launch_bounds__(256) void lpg_fwd_kernel(const float* __restrict__ plane, int B, int h, int w,
+__global__ __launch_bounds__(64 * LPG_ROWS) void lpg_fwd_kernel(const float* __restrict__ plane, int B, int h, int w,
                                                       int normalize, float max_depth,
                                                       float* __restrict__ out, float* __restrict__ ds_out,
                                                       int ds_factor, long ds_pix_stride,
@@ -60,9 +64,10 @@ __global__ __launch_bounds__(256) void lpg_fwd_kernel(const float* __restrict__ 
     const int W4 = W / V;                        // V = 4 when W % 4 == 0 (16-byte stores), else 1
     const int nrows = B * H;
     float amin = __uint_as_float(0x7f800000u);
-    // block = 64 x 4: a wave walks one output row in 64-wide strides (coalesced 1 KiB stores), so the
+    // block = 64 x 16: a wave walks one output row in 64-wide strides (coalesced 1 KiB stores), so the
     // (b, r) decode costs one division per row instead of two per element.
-    for (int row = blockIdx.x * 4 + threadIdx.y; row < nrows; row += gridDim.x * 4)
+    [[maybe_unused]] const float inv_scale_den = max_depth;         // FUSED: depth/max_depth == n4 / (den * max_depth)
+    for (int row = blockIdx.x * LPG_ROWS + threadIdx.y; row < nrows; row += gridDim.x * LPG_ROWS)
     for (int c4 = threadIdx.x; c4 < W4; c4 += 64) {
         const int r = row % H;
         const int b = row / H;
@@ -133,9 +138,9 @@ int launch_lpg(const float* plane, int B, int h, int w, int k, int normalize, fl
     }
     const bool vec4 = (((long)w * k) % 4) == 0;
     if ((long)B * h * k > 0x7fffffffL) return BTS_ERR_UNSUPPORTED;
-    long blocks = ((long)B * h * k + 3) / 4;
-    if (blocks > 1024) blocks = 1024;                // <= 1024 same-address atomics (see publish_abs_min)
-    dim3 grid((unsigned)blocks), block(64, 4);
+    long blocks = ((long)B * h * k + LPG_ROWS - 1) / LPG_ROWS;
+    if (blocks > 512) blocks = 512;                  // <= 512 same-address atomics (see publish_abs_min); 2 blocks/CU
+    dim3 grid((unsigned)blocks), block(64, LPG_ROWS);
 #define LPG_LAUNCH(KK)                                                                                          \
     if (vec4)                                                                                                   \
         hipLaunchKernelGGL((lpg_fwd_kernel<KK, 4, PLANAR, FUSED>), grid, block, 0, s, plane, B, h, w, normalize, \
