@@ -121,6 +121,11 @@ def cpu_baseline(params, H, W, seconds_budget=15.0):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL does at init) are
+    # sent to stderr for the whole run; the JSON goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -145,8 +150,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("BTS_BENCH_FORCE_DIST"))   # FORCE: exercise RCCL with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
@@ -206,7 +215,7 @@ def main():
                 graph = None
                 torch.cuda.synchronize()
 
-        gather = world > 1 and not args.no_gather
+        gather = use_dist and not args.no_gather
         pending = [None]
 
         def step():
@@ -227,7 +236,7 @@ def main():
             pending[0][1].wait()
             pending[0] = None
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -235,11 +244,11 @@ def main():
         if pending[0] is not None:
             pending[0][1].wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         log("timed %d steps: %.3f ms/step" % (args.steps, 1e3 * elapsed / args.steps))
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
@@ -328,8 +337,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")
             line["cpu_baseline"] = cpu_baseline(params, H, W)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

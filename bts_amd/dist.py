@@ -24,7 +24,7 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 def broadcast_module(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 64 << 20):
     """Broadcast parameters + buffers from ``src`` in flat fp32 buckets (one-time start-up cost)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     by_dtype = {}
@@ -50,7 +50,7 @@ def all_gather_depths(outs: Sequence[torch.Tensor], n_maps: int = 5, async_op: b
     """Gather the first ``n_maps`` outputs ([b,1,H,W] each) of every rank: returns ([world,n_maps,b,1,H,W], work).
     One packed buffer -> ONE collective per step instead of five."""
     packed = torch.stack([o for o in outs[:n_maps]], dim=0).contiguous()
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return packed.unsqueeze(0), None
     world = dist.get_world_size()
     gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
