@@ -148,6 +148,29 @@ def test_bts_test_py_call_protocol(tmp_path):
     sys.path.remove(model_dir)
 
 
+def test_graphed_model_replay_matches_eager():
+    """bts_amd.graph.GraphedModel: capture once per shape, replay for new inputs; same bits as the eager forward."""
+    from bts_amd import bts as M
+    from bts_amd.graph import GraphedModel
+    params = Params("densenet161_bts", 512, 80.0, "kitti")
+    torch.manual_seed(6)
+    m = M.BtsModel(params).eval().cuda()
+    gm = GraphedModel(m)
+    with torch.no_grad():
+        for seed in (1, 2, 3):
+            x = torch.from_numpy(synth.image_batch(2, 64, 96, seed)).cuda()
+            focal = torch.from_numpy(synth.focal_values(2, "kitti", seed)).cuda()
+            ref = [o.clone() for o in m(x, focal)]
+            got = gm(x, focal)
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(ref, got)), "graph replay differs (seed %d)" % seed
+        assert len(gm._graphs) == 1
+        x2 = torch.from_numpy(synth.image_batch(1, 32, 64, 9)).cuda()          # a second shape gets its own graph
+        f2 = torch.from_numpy(synth.focal_values(1, "kitti", 9)).cuda()
+        assert all(torch.equal(a, b) for a, b in zip([o.clone() for o in m(x2, f2)], gm(x2, f2)))
+        assert len(gm._graphs) == 2
+
+
 def test_pooling_kernels():
     from bts_amd import ops
     import torch.nn.functional as F
