@@ -124,6 +124,60 @@ __global__ __launch_bounds__(64 * LPG_ROWS) void lpg_fwd_kernel(const float* __r
     if (abs_min_bits != nullptr) publish_abs_min(amin, abs_min_bits);
 }
 
+// Lean kernel for the decoder pipeline's case (planes already normalised by the reduction epilogue, W % 4 == 0,
+// K in {2,4,8}): ~45 VALU per 16-byte store instead of ~200 in the general kernel (whose runtime `normalize`
+// branch carries IEEE divisions and whose indices are 64-bit) -- the general kernel was VALU-bound at 2.7 TB/s
+// where a plain fill reaches 6.9 TB/s on this device.  Not the bit-exact path: den uses FMAs and one hardware
+// reciprocal replaces the two IEEE divisions (<= ~1.5 ulp; the module-level op stays exact).
+template <int K>
+__global__ __launch_bounds__(64 * LPG_ROWS) void lpg_fused_lean_kernel(const float4* __restrict__ plane4, int nrows, int H,
+                                                                       int h, int w, float max_depth,
+                                                                       float* __restrict__ out, float* __restrict__ ds_out,
+                                                                       int ds_factor, int ds_pix_stride,
+                                                                       unsigned* __restrict__ abs_min_bits) {
+    const int W = w * K, W4 = W >> 2;
+    constexpr float invK = 1.0f / (float)K;
+    constexpr int CELLS = K >= 4 ? 1 : 2;
+    float amin = __uint_as_float(0x7f800000u);
+    for (int row = blockIdx.x * LPG_ROWS + threadIdx.y; row < nrows; row += gridDim.x * LPG_ROWS) {
+        const int b = row / H, r = row - b * H;
+        const int cr = r / K;
+        const float v = ((float)(r - cr * K) - (float)(K - 1) * 0.5f) * invK;
+        const float4* prow = plane4 + (size_t)(b * h + cr) * w;
+        float* orow = out + (size_t)row * W;
+        const bool ds_row = ds_out != nullptr && (r % ds_factor) == 0;
+        float* dsrow = ds_row ? ds_out + (size_t)((b * (H / ds_factor) + r / ds_factor) * (W / ds_factor)) * ds_pix_stride : nullptr;
+        for (int c4 = threadIdx.x; c4 < W4; c4 += 64) {
+            const int c0 = c4 * 4;
+            float res[4];
+#pragma unroll
+            for (int ci = 0; ci < CELLS; ++ci) {
+                const int cb = c0 + ci * (4 / CELLS);
+                const float4 q = prow[cb / K];
+                const float base = fmaf(q.y, v, q.z);                       // n2*v + n3
+                const float u0 = ((float)(cb % K) - (float)(K - 1) * 0.5f) * invK;
+#pragma unroll
+                for (int i = 0; i < 4 / CELLS; ++i) {
+                    float d = fmaf(q.x, u0 + (float)i * invK, base);        // n1*u + n2*v + n3   (bts.py:166)
+                    amin = fminf(amin, fabsf(d));                           // bts.py:167
+                    d = lpg_clamp(d);                                       // bts.py:168-171
+                    res[ci * (4 / CELLS) + i] = q.w * __builtin_amdgcn_rcpf(d * max_depth);   // bts.py:173,255
+                }
+            }
+            *reinterpret_cast<float4*>(orow + c0) = make_float4(res[0], res[1], res[2], res[3]);
+            if (ds_row) {                                                   // nearest [::f, ::f]   (bts.py:256,270)
+                if (ds_factor == 4) dsrow[(size_t)c4 * ds_pix_stride] = res[0];
+                else if (ds_factor == 2) { dsrow[(size_t)(2 * c4) * ds_pix_stride] = res[0]; dsrow[(size_t)(2 * c4 + 1) * ds_pix_stride] = res[2]; }
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dsrow[(size_t)(c0 + i) * ds_pix_stride] = res[i];
+                }
+            }
+        }
+    }
+    if (abs_min_bits != nullptr) publish_abs_min(amin, abs_min_bits);
+}
+
 template <bool PLANAR, bool FUSED>
 int launch_lpg(const float* plane, int B, int h, int w, int k, int normalize, float max_depth, float* out,
                float* ds_out, int ds_factor, long ds_pix_stride, float* abs_min, hipStream_t s) {
@@ -141,6 +195,17 @@ int launch_lpg(const float* plane, int B, int h, int w, int k, int normalize, fl
     long blocks = ((long)B * h * k + LPG_ROWS - 1) / LPG_ROWS;
     if (blocks > 512) blocks = 512;                  // <= 512 same-address atomics (see publish_abs_min); 2 blocks/CU
     dim3 grid((unsigned)blocks), block(64, LPG_ROWS);
+    if (FUSED && !PLANAR && !normalize && vec4 && k >= 2 && (ds_out == nullptr || ds_factor == 1 || ds_factor == 2 || ds_factor == 4) &&
+        ds_pix_stride <= 0x7fffffffL && (long)B * h * k * w * k <= 0x7fffffffL) {
+        const float4* p4 = reinterpret_cast<const float4*>(plane);
+        const int nrows = B * h * k, H = h * k, dss = (int)ds_pix_stride;
+        switch (k) {
+            case 2: hipLaunchKernelGGL(lpg_fused_lean_kernel<2>, grid, block, 0, s, p4, nrows, H, h, w, max_depth, out, ds_out, ds_factor, dss, bits); break;
+            case 4: hipLaunchKernelGGL(lpg_fused_lean_kernel<4>, grid, block, 0, s, p4, nrows, H, h, w, max_depth, out, ds_out, ds_factor, dss, bits); break;
+            default: hipLaunchKernelGGL(lpg_fused_lean_kernel<8>, grid, block, 0, s, p4, nrows, H, h, w, max_depth, out, ds_out, ds_factor, dss, bits); break;
+        }
+        return (int)hipGetLastError();
+    }
 #define LPG_LAUNCH(KK)                                                                                          \
     if (vec4)                                                                                                   \
         hipLaunchKernelGGL((lpg_fwd_kernel<KK, 4, PLANAR, FUSED>), grid, block, 0, s, plane, B, h, w, normalize, \
