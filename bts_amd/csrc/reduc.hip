@@ -154,6 +154,153 @@ int launch_reduc(const float* x, long stride, long npix, const float* w_frag, lo
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 16x16x4-MFMA variant for the narrow chains (2x2: 64->32->16->8->3, 1x1: 32->16->8->1).  Same chaining trick:
+// D of v_mfma_f32_16x16x4_f32 has the pixel on lane&15 and out-channel 4*(lane>>4)+r in register r, which is
+// exactly the B operand of the next layer's k-step r (channel 16*mt + 4*kq + r).  A wave owns 64 pixels as four
+// 16-pixel tiles that share every weight fragment; layers of <= 16 outputs cost one 16-row tile instead of a
+// padded 32-row one (1x1 chain: 32 instead of 56 MFMA-cycles per pixel), a lane loads 64-byte pixel segments
+// (32-byte ones in the 32x32 kernel), and the sigmoid/sin/cos epilogue is re-spread over all 64 lanes.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#ifndef RT2
+#define RT2 2     // 16-pixel tiles per wave for the 2x2 chain
+#endif
+#ifndef RT1
+#define RT1 4     // ... for the 1x1 chain
+#endif
+
+template <int NT, int K, int MT, int NX>
+__device__ __forceinline__ void dense_layer16(const float4* __restrict__ wf, int lane, const float (&x)[NT][NX],
+                                              f32x4v (&acc)[MT][NT]) {
+    constexpr int G = (K + 15) / 16;
+    static_assert(NX >= 4 * G, "activation registers");
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float4 w = wf[(mt * G + g) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x[t][4 * g + 0], acc[mt][t], 0, 0, 0);
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x[t][4 * g + 1], acc[mt][t], 0, 0, 0);
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x[t][4 * g + 2], acc[mt][t], 0, 0, 0);
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x[t][4 * g + 3], acc[mt][t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// (K, M) walk as in reduction_1x1.__init__ (bts.py:105-122); o[t][c] = channel c of the last layer for pixel tile t
+// (valid on lanes < 16: out-channel 4*(lane>>4)+r lives in register r).
+template <int NT, int K, int M, int NX>
+__device__ __forceinline__ void chain16(const float4* __restrict__ wf, int lane, const float (&x)[NT][NX], float (&o)[NT][3]) {
+    constexpr int G = (K + 15) / 16;
+    if constexpr (M < 8) {
+        f32x4v acc[1][NT];
+        dense_layer16<NT, K, 1, NX>(wf, lane, x, acc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { o[t][0] = acc[0][t][0]; o[t][1] = acc[0][t][1]; o[t][2] = acc[0][t][2]; }
+    } else {
+        constexpr int MT = (M + 15) / 16;
+        f32x4v acc[MT][NT];
+        dense_layer16<NT, K, MT, NX>(wf, lane, x, acc);
+        float y[NT][4 * MT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[t][4 * mt + r] = elu1(acc[mt][t][r]);     // rows >= M are exact zeros
+        chain16<NT, M, M / 2, 4 * MT>(wf + MT * G * 64, lane, y, o);
+    }
+}
+
+template <int C0, int M0>
+constexpr long chain16_frag_float4s() {
+    long n = 0;
+    int k = C0, m = M0;
+    while (m >= 8) { n += (long)((m + 15) / 16) * ((k + 15) / 16) * 64; k = m; m = m / 2; }
+    n += (long)((k + 15) / 16) * 64;
+    return n;
+}
+
+// NT = 16-pixel tiles per wave (4: 64 pixels, all lanes busy in the epilogue; 2: half the registers, more waves)
+template <int C0, int M0, bool FINAL, int NT>
+__global__ __launch_bounds__(512) void reduc16_fwd_kernel(const float* __restrict__ x, long x_pix_stride, long npix,
+                                                          const float4* __restrict__ w_frag, float max_depth,
+                                                          int normalize, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float4* wl = reinterpret_cast<float4*>(smem_raw);
+    constexpr long NW = chain16_frag_float4s<C0, M0>();
+    for (long i = threadIdx.x; i < NW; i += blockDim.x) wl[i] = w_frag[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwav = blockDim.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    constexpr int PXW = 16 * NT;                          // pixels per wave-group
+    const long ngroups = (npix + PXW - 1) / PXW;
+    for (long grp = (long)blockIdx.x * nwav + wave; grp < ngroups; grp += (long)gridDim.x * nwav) {
+        const long p0 = grp * PXW;
+        float xr[NT][C0 / 4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const long p = p0 + 16 * t + j;
+            const bool live = p < npix;
+            const float* xp = x + (live ? p : 0) * x_pix_stride + 4 * q;
+#pragma unroll
+            for (int g = 0; g < C0 / 16; ++g) {          // lane (j,q): channels 16g + 4q .. +3
+                const float4 v = live ? *reinterpret_cast<const float4*>(xp + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xr[t][4 * g + 0] = v.x; xr[t][4 * g + 1] = v.y; xr[t][4 * g + 2] = v.z; xr[t][4 * g + 3] = v.w;
+            }
+        }
+        float o[NT][3];
+        chain16<NT, C0, M0, C0 / 4>(wl, lane, xr, o);
+        // pixel p0 + lane's parameters sit on lane (lane & 15) of tile (lane >> 4): one shuffle per value
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float a0 = __shfl(o[t][0], j, 64), a1 = __shfl(o[t][1], j, 64), a2 = __shfl(o[t][2], j, 64);
+            if (q == t) { c0 = a0; c1 = a1; c2 = a2; }
+        }
+        const long p = p0 + lane;
+        if (lane < PXW && p < npix) {
+            if (FINAL) {
+                out[p] = sigmoid1(c0);                                          // bts.py:108-110
+            } else {
+                const float PI = 3.14159265358979323846f;
+                const float theta = sigmoid1(c0) * PI / 3.f;                    // bts.py:127
+                const float phi = sigmoid1(c1) * PI * 2.f;                      // bts.py:128
+                const float dist = sigmoid1(c2) * max_depth;                    // bts.py:129
+                float n1 = sinf(theta) * cosf(phi);                             // bts.py:130
+                float n2 = sinf(theta) * sinf(phi);                             // bts.py:131
+                float n3 = cosf(theta);                                         // bts.py:132
+                if (normalize) {                                                // bts.py:251
+                    const float nn = fmaxf(sqrtf(n1 * n1 + n2 * n2 + n3 * n3), 1e-12f);
+                    n1 /= nn; n2 /= nn; n3 /= nn;
+                }
+                *reinterpret_cast<float4*>(out + p * 4) = make_float4(n1, n2, n3, dist);
+            }
+        }
+    }
+}
+
+template <int C0, int M0, bool FINAL, int NT>
+int launch_reduc16(const float* x, long stride, long npix, const float* w_frag, long w_frag_floats, float max_depth,
+                   int normalize, float* out, hipStream_t s) {
+    constexpr long NW = chain16_frag_float4s<C0, M0>();
+    if (w_frag_floats != NW * 4) return BTS_ERR_INVALID;
+    const size_t lds = (size_t)NW * 16;
+    const long ngroups = (npix + 16 * NT - 1) / (16 * NT);
+    long blocks = (ngroups + 7) / 8;
+    if (blocks > 256L * 4) blocks = 256L * 4;
+    hipLaunchKernelGGL((reduc16_fwd_kernel<C0, M0, FINAL, NT>), dim3((unsigned)blocks), dim3(512), lds, s, x, stride, npix,
+                       reinterpret_cast<const float4*>(w_frag), max_depth, normalize, out);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" int bts_reduc_fwd_f32(const float* x, long x_pix_stride, long npix, int c_in, int c_first_out,
@@ -169,11 +316,11 @@ extern "C" int bts_reduc_fwd_f32(const float* x, long x_pix_stride, long npix, i
             return launch_reduc<128, 128, false>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
         if (c_in == 128 && c_first_out == 64)
             return launch_reduc<128, 64, false>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
-        if (c_in == 64 && c_first_out == 32)
-            return launch_reduc<64, 32, false>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
+        if (c_in == 64 && c_first_out == 32)       // narrow chains: 16x16x4-MFMA kernel (fragments from pack_reduc_weights)
+            return launch_reduc16<64, 32, false, RT2>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
     } else {
         if (c_in == 32 && c_first_out == 16)
-            return launch_reduc<32, 16, true>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
+            return launch_reduc16<32, 16, true, RT1>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
     }
     return BTS_ERR_UNSUPPORTED;
 }

@@ -172,21 +172,37 @@ def reduc_chain(num_in: int, num_out: int) -> List[Tuple[int, int]]:
     return layers
 
 
+def reduc_uses_mfma16(c_in: int, c_first_out: int) -> bool:
+    """The narrow chains (2x2: 64->32.., 1x1: 32->16..) run on the 16x16x4-MFMA kernel (csrc/reduc.hip)."""
+    return (c_in, c_first_out) in ((64, 32), (32, 16))
+
+
 def pack_reduc_weights(weights: Sequence[torch.Tensor]) -> torch.Tensor:
     """Pack a reduction chain's 1x1 weights ([cout,cin,1,1] each) into MFMA fragment order.
 
-    Per layer (K=cin, rows padded to 32*MT): float4 index ((mt*(K/8)+g)*64 + 32*h + i) holds
-    W[32*mt+i][4*(2g+h) + 0..3]  -- lane (i,h) of v_mfma_f32_32x32x2_f32's A operand for the four
-    k-steps of group g (see csrc/reduc.hip)."""
+    Wide chains (first layer 128 -> ..): per layer (K=cin, rows padded to 32*MT) float4 index
+    ((mt*(K/8)+g)*64 + 32*h + i) holds W[32*mt+i][4*(2g+h) + 0..3] -- lane (i,h) of v_mfma_f32_32x32x2_f32's A operand
+    for the four k-steps of group g.  Narrow chains (see reduc_uses_mfma16): rows padded to 16*MT, K to 16*G, float4
+    index ((mt*G+g)*64 + 16*kq + i) holds W[16*mt+i][16*g + 4*kq + 0..3] -- lane (i,kq) of v_mfma_f32_16x16x4_f32."""
+    c_in = weights[0].shape[1]
+    c_first = weights[0].shape[0]
+    narrow = reduc_uses_mfma16(c_in, c_first)
     parts = []
     for w in weights:
         cout, cin = w.shape[0], w.shape[1]
         assert cin % 8 == 0, "reduction chain widths are multiples of 8"
-        mt = (cout + 31) // 32
-        wp = torch.zeros((mt * 32, cin), dtype=torch.float32, device=w.device)
-        wp[:cout] = w.reshape(cout, cin).float()
-        # (mt, i, g, h, q) -> (mt, g, h, i, q)
-        parts.append(wp.view(mt, 32, cin // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1))
+        if narrow:
+            mt, g = (cout + 15) // 16, (cin + 15) // 16
+            wp = torch.zeros((mt * 16, g * 16), dtype=torch.float32, device=w.device)
+            wp[:cout, :cin] = w.reshape(cout, cin).float()
+            # (mt, i, g, kq, q4) -> (mt, g, kq, i, q4)
+            parts.append(wp.view(mt, 16, g, 4, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1))
+        else:
+            mt = (cout + 31) // 32
+            wp = torch.zeros((mt * 32, cin), dtype=torch.float32, device=w.device)
+            wp[:cout] = w.reshape(cout, cin).float()
+            # (mt, i, g, h, q) -> (mt, g, h, i, q)
+            parts.append(wp.view(mt, 32, cin // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1))
     return torch.cat(parts).contiguous()
 
 

@@ -99,13 +99,24 @@ def test_pack_layouts():
     perm = torch.tensor([4, 0, 1, 2, 3])
     pp, _, _ = ops.pack_conv_weight(w, perm=perm)
     assert pp[1, 4 * 8 + 0] == w[1, 4, 1, 1]
-    # reduction fragments: float4 ((mt*(K/8)+g)*64 + 32h + i) = W[32mt+i][4(2g+h) .. +3]
-    w1 = torch.arange(16 * 32, dtype=torch.float32).reshape(16, 32, 1, 1)
-    f = ops.pack_reduc_weights([w1]).view(-1, 4)
-    K = 32
-    for (mt, g, h, i) in ((0, 0, 0, 0), (0, 1, 1, 5), (0, 3, 0, 15), (0, 2, 1, 20)):
+    # wide-chain fragments (32x32x2 MFMA): float4 ((mt*(K/8)+g)*64 + 32h + i) = W[32mt+i][4(2g+h) .. +3]
+    ww = torch.arange(64 * 128, dtype=torch.float32).reshape(64, 128, 1, 1)
+    f = ops.pack_reduc_weights([ww]).view(-1, 4)
+    K = 128
+    for (mt, g, h, i) in ((0, 0, 0, 0), (1, 5, 1, 7), (0, 15, 0, 31), (1, 2, 1, 20)):
         got = f[(mt * (K // 8) + g) * 64 + 32 * h + i]
-        exp = w1[i, 4 * (2 * g + h):4 * (2 * g + h) + 4, 0, 0] if i < 16 else torch.zeros(4)
-        assert torch.equal(got, exp)
+        assert torch.equal(got, ww[32 * mt + i, 4 * (2 * g + h):4 * (2 * g + h) + 4, 0, 0])
+    # narrow-chain fragments (16x16x4 MFMA): float4 ((mt*G+g)*64 + 16kq + i) = W[16mt+i][16g + 4kq .. +3], zero padded
+    w1 = torch.arange(16 * 32, dtype=torch.float32).reshape(16, 32, 1, 1) + 1
+    w2 = torch.arange(8 * 16, dtype=torch.float32).reshape(8, 16, 1, 1) + 1
+    w3 = torch.arange(1 * 8, dtype=torch.float32).reshape(1, 8, 1, 1) + 1
+    assert ops.reduc_uses_mfma16(32, 16) and not ops.reduc_uses_mfma16(128, 64)
+    f = ops.pack_reduc_weights([w1, w2, w3]).view(-1, 4)
+    assert f.shape[0] == (2 + 1 + 1) * 64
+    for (g, kq, i) in ((0, 0, 0), (1, 3, 15), (0, 2, 9)):
+        assert torch.equal(f[g * 64 + 16 * kq + i], w1[i, 16 * g + 4 * kq:16 * g + 4 * kq + 4, 0, 0])
+    l2, l3 = f[128:192], f[192:256]
+    assert torch.equal(l2[16 * 1 + 3], w2[3, 4:8, 0, 0]) and l2[16 * 1 + 9].abs().sum() == 0      # rows 8..15 are padding
+    assert torch.equal(l3[16 * 1 + 0], w3[0, 4:8, 0, 0]) and l3[16 * 2 + 0].abs().sum() == 0      # k 8..15 are padding
     assert ops.reduc_chain(128, 128) == [(128, 128), (128, 64), (64, 32), (32, 16), (16, 8), (8, -1)]
     assert synth.reduc_chain_channels(32, 16, True) == [32, 16, 8, 1]
