@@ -29,7 +29,10 @@
 namespace {
 
 constexpr int BK = 32;
-constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
+// floats per LDS row (32 + pad), chosen per MFMA shape so that the 16 rows a ds_read_b128 lane group touches
+// land in 16 distinct 16-B bank slots: 36 (slot = 9*row) for the 32x32 lane map, 40 (slot = 10*row + k-quarter)
+// for the 16x16 one -- 36 is 2-way conflicted there (SQ_LDS_BANK_CONFLICT, profiles/r01_pmc_mfma.json)
+template <int MF> struct LdsLd { static constexpr int value = MF == 32 ? 36 : 40; };
 
 struct ConvArgs {
     const float* x; long x_pix_stride; int c_in_ld; int k_pad;   // k_pad: padded flattened K (taps*c_in_ld rounded to 32)
@@ -138,7 +141,7 @@ __device__ __forceinline__ void issue_loads_fast(const ConvArgs& a, const float*
 }
 
 // Prologue (BN affine + ReLU, reference bts.py:70,72) and zero padding, applied on the way to LDS.
-template <int BM, int BN, int RPP, int PA, int PB>
+template <int BM, int BN, int RPP, int PA, int PB, int LDS_LD>
 __device__ __forceinline__ void stage_to_lds(const ConvArgs& a, float* __restrict__ As, int lrow, int lk,
                                              const f32x4 (&ra)[PA], const f32x4 (&rb)[PB], const f32x4& ps,
                                              const f32x4& pb, unsigned okmask) {
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     constexpr int RPP = NT / 8;               // tile rows staged per pass (8 lanes x 16 B per row)
     constexpr int TM = BM / WM / MF, TN = BN / WN / MF;
     constexpr int PA = BM / RPP, PB = (BN + RPP - 1) / RPP;
+    constexpr int LDS_LD = LdsLd<MF>::value;
     constexpr int NACC = MF == 32 ? 16 : 4;   // accumulator registers per tile
     typedef float acc_t __attribute__((ext_vector_type(NACC)));
     static_assert(BM % RPP == 0 && BM % (WM * MF) == 0 && BN % (WN * MF) == 0, "tile/wave layout");
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
         }
     };
     issue(0);
-    stage_to_lds<BM, BN, RPP, PA, PB>(a, smem, lrow, lk, ra, rb, ps, pb, okmask);
+    stage_to_lds<BM, BN, RPP, PA, PB, LDS_LD>(a, smem, lrow, lk, ra, rb, ps, pb, okmask);
     if (nit > 1) issue(1);
     __syncthreads();
 
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
                     }
             if (g == 0) {     // after the first MFMA group: the staging VALU / ds_writes / address math issue in the
                               // shadow of the remaining groups; the new loads still get ~a full step to land
-                if (it + 1 < nit) stage_to_lds<BM, BN, RPP, PA, PB>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
+                if (it + 1 < nit) stage_to_lds<BM, BN, RPP, PA, PB, LDS_LD>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
                 if (it + 2 < nit) issue(it + 2);
             }
         }
@@ -446,7 +450,7 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     }
     const long nwg = tiles * a.ksplit;
     if (nwg > 0x7fffffffL) return BTS_ERR_INVALID;
-    size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    size_t lds = (size_t)2 * (BM + BN) * LdsLd<MF>::value * sizeof(float);
     if (const char* f = getenv("BTS_CONV_LDS_KB")) {   // tuning aid: inflate LDS to limit workgroups per CU
         const size_t v = (size_t)atoi(f) * 1024;
         if (v > lds && v <= 160 * 1024) lds = v;

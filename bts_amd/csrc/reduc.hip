@@ -166,7 +166,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define RT2 2     // 16-pixel tiles per wave for the 2x2 chain
 #endif
 #ifndef RT1
-#define RT1 4     // ... for the 1x1 chain
+#define RT1 2     // ... for the 1x1 chain
 #endif
 
 template <int NT, int K, int MT, int NX>
