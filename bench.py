@@ -88,7 +88,7 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(params, H, W, seconds_budget=15.0):
+def cpu_baseline(params, H, W, seconds_budget=15.0, gpu_frame0=None):
     """The oracle (CPU restatement, oracle/bts_oracle.py) + the same torch encoder on the host cores.
     Bounded sample: B=1 frames of the same 352x1216 workload until ~seconds_budget is spent."""
     from bts_amd import bts as M, synth
@@ -102,22 +102,45 @@ def cpu_baseline(params, H, W, seconds_budget=15.0):
     img = torch.from_numpy(synth.image_batch(1, H, W, 1234))
     focal = torch.from_numpy(synth.focal_values(1, params.dataset, 1234))
     times = []
+    parity = None
     with torch.no_grad():
         t_all = time.perf_counter()
         for i in range(40):
             t0 = time.perf_counter()
             feats = enc(img)
-            O.decoder_forward(state, feats, focal, params.max_depth, params.dataset)
+            ref = O.decoder_forward(state, feats, focal, params.max_depth, params.dataset, want_intermediates=(i == 0))
             dt = time.perf_counter() - t0
+            if i == 0 and gpu_frame0 is not None:
+                # parity gate of THIS run: frame 0 of the GPU batch (same PCG64 image, same weights) vs the CPU oracle
+                outs, inter = ref
+                names = ("depth_8x8_scaled", "depth_4x4_scaled", "depth_2x2_scaled", "reduc1x1", "final_depth")
+                parity = {"tolerance": 1e-3, "frame": 0}
+                near = 0
+                for j, nm in enumerate(names):
+                    g = gpu_frame0[j].double().cpu().numpy()
+                    r = outs[j][0:1].double().numpy()
+                    mask = np.ones(r.shape, dtype=bool)
+                    if j < 3:
+                        k = (8, 4, 2)[j]
+                        den = O.lpg_denominator(inter["plane_eq_%dx%d" % (k, k)], k).unsqueeze(1).numpy()
+                        mask = np.abs(den) > 2e-3          # near the +-1e-3 clamp relative error is meaningless
+                        near += int((~mask).sum())
+                    parity[nm] = float(np.max(np.abs(g - r)[mask] / np.maximum(np.abs(r)[mask], 1e-30)))
+                ic = np.abs(gpu_frame0[5].double().cpu().numpy() - outs[5][0:1].double().numpy())
+                parity["iconv1_max_abs"] = float(ic.max())
+                parity["near_singular_lpg_px_masked"] = near
+                parity["ok"] = bool(max(parity[n] for n in names) <= 1e-3)
+                log("parity vs CPU oracle (frame 0): " + ", ".join("%s %.2e" % (n, parity[n]) for n in names))
             log("cpu frame %d: %.2f s" % (i, dt))
             if i > 0:
                 times.append(dt)
             if time.perf_counter() - t_all > seconds_budget and len(times) >= 2:
                 break
     med = float(np.median(times))
-    return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "B=1 x %d timed frames (1 warm-up) of the same 3x%dx%d fp32 workload, torch %s CPU encoder + "
-                      "oracle decoder, median" % (len(times), H, W, torch.__version__)}
+    out = {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "B=1 x %d timed frames (1 warm-up) of the same 3x%dx%d fp32 workload, torch %s CPU encoder + "
+                     "oracle decoder, median" % (len(times), H, W, torch.__version__)}
+    return out, parity
 
 
 def main():
@@ -336,7 +359,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")
-            line["cpu_baseline"] = cpu_baseline(params, H, W)
+            frame0 = None
+            if not args.decoder_only and rank == 0:
+                with torch.no_grad():
+                    frame0 = [o[0:1].clone() for o in model(image[0:1], focal[0:1])]
+                torch.cuda.synchronize()
+            line["cpu_baseline"], par = cpu_baseline(params, H, W, gpu_frame0=frame0)
+            if par is not None:
+                line["parity"] = par
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if use_dist:
