@@ -47,34 +47,32 @@ def weights_init_xavier(m):
 
 
 class silog_loss(nn.Module):
-    """bts.py:41-48 (plain torch; used by training callers, not on the inference hot path)."""
+    """Scale-invariant log loss, same value as reference bts.py:41-48 (plain torch; training callers only)."""
 
     def __init__(self, variance_focus):
-        super(silog_loss, self).__init__()
+        super().__init__()
         self.variance_focus = variance_focus
 
     def forward(self, depth_est, depth_gt, mask):
-        d = torch.log(depth_est[mask]) - torch.log(depth_gt[mask])
-        return torch.sqrt((d ** 2).mean() - self.variance_focus * (d.mean() ** 2)) * 10.0
+        log_ratio = depth_est[mask].log() - depth_gt[mask].log()
+        second_moment, first_moment = log_ratio.pow(2).mean(), log_ratio.mean()
+        return 10.0 * torch.sqrt(second_moment - self.variance_focus * first_moment * first_moment)
 
 
 class depth_l1_loss(nn.Module):
-    """bts.py:50-63."""
+    """Asymmetric L1 depth loss, same value as reference bts.py:50-63: over-estimates are weighted by
+    ``inbalance_to_closer``; the mean runs over ALL masked pixels."""
 
     def __init__(self, inbalance_to_closer):
-        super(depth_l1_loss, self).__init__()
+        super().__init__()
         self.inbalance_to_closer = inbalance_to_closer
 
     def forward(self, depth_est, depth_gt, mask):
+        err = depth_est[mask] - depth_gt[mask]
         if self.inbalance_to_closer == 1:
-            d = torch.abs(depth_est[mask] - depth_gt[mask]).mean()
-        else:
-            err = depth_est[mask] - depth_gt[mask]
-            err_pos = self.inbalance_to_closer * err[err > 0]
-            err_neg = -err[err < 0]
-            total_num = err.numel()
-            d = (err_pos.sum() + err_neg.sum()) / total_num
-        return d
+            return err.abs().mean()
+        weighted = torch.where(err > 0, self.inbalance_to_closer * err, -err)
+        return weighted.sum() / err.numel()
 
 
 def _bn_vecs(bn: nn.BatchNorm2d, n_pad: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -109,18 +107,18 @@ class atrous_conv(nn.Sequential):
     """bts.py:65-80.  Same sub-module tree (atrous_conv.first_bn / aconv_sequence.{1,2,4})."""
 
     def __init__(self, in_channels, out_channels, dilation, apply_bn_first=True):
-        super(atrous_conv, self).__init__()
-        self.atrous_conv = torch.nn.Sequential()
+        super().__init__()
+        mid = 2 * out_channels
+        branch = nn.Sequential()                     # registration order fixes the checkpoint keys
         if apply_bn_first:
-            self.atrous_conv.add_module('first_bn', nn.BatchNorm2d(in_channels, momentum=0.01, affine=True,
-                                                                   track_running_stats=True, eps=1.1e-5))
-        self.atrous_conv.add_module('aconv_sequence', nn.Sequential(
-            nn.ReLU(),
-            nn.Conv2d(in_channels=in_channels, out_channels=out_channels * 2, bias=False, kernel_size=1, stride=1, padding=0),
-            nn.BatchNorm2d(out_channels * 2, momentum=0.01, affine=True, track_running_stats=True),
-            nn.ReLU(),
-            nn.Conv2d(in_channels=out_channels * 2, out_channels=out_channels, bias=False, kernel_size=3, stride=1,
-                      padding=(dilation, dilation), dilation=dilation)))
+            branch.add_module('first_bn', nn.BatchNorm2d(in_channels, eps=1.1e-5, momentum=0.01))
+        branch.add_module('aconv_sequence', nn.Sequential(
+            nn.ReLU(),                                                                     # .0
+            nn.Conv2d(in_channels, mid, kernel_size=1, bias=False),                        # .1
+            nn.BatchNorm2d(mid, momentum=0.01),                                            # .2
+            nn.ReLU(),                                                                     # .3
+            nn.Conv2d(mid, out_channels, kernel_size=3, padding=dilation, dilation=dilation, bias=False)))   # .4
+        self.atrous_conv = branch
         self.dilation = dilation
         self.apply_bn_first = apply_bn_first
         self._pack = None
@@ -162,9 +160,9 @@ class upconv(nn.Module):
     """bts.py:83-94: nearest x2 (folded into the conv's gather) -> conv3x3 -> ELU."""
 
     def __init__(self, in_channels, out_channels, ratio=2):
-        super(upconv, self).__init__()
-        self.elu = nn.ELU()
-        self.conv = nn.Conv2d(in_channels=in_channels, out_channels=out_channels, bias=False, kernel_size=3, stride=1, padding=1)
+        super().__init__()
+        self.elu = nn.ELU()          # parameter-free; kept so the module tree prints like the reference's
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, bias=False)
         self.ratio = ratio
         self._pack = None
         self._pack_key = None
@@ -196,30 +194,21 @@ class reduction_1x1(nn.Sequential):
     """bts.py:97-136.  Same ``reduc`` sub-module names (inter_<in>_<out>, plane_params / final)."""
 
     def __init__(self, num_in_filters, num_out_filters, max_depth, is_final=False):
-        super(reduction_1x1, self).__init__()
+        super().__init__()
         self.max_depth = max_depth
         self.is_final = is_final
         self.sigmoid = nn.Sigmoid()
-        self.reduc = torch.nn.Sequential()
         self.c_in, self.c_first_out = num_in_filters, num_out_filters
-
-        while num_out_filters >= 4:
-            if num_out_filters < 8:
-                if self.is_final:
-                    self.reduc.add_module('final', torch.nn.Sequential(
-                        nn.Conv2d(num_in_filters, out_channels=1, bias=False, kernel_size=1, stride=1, padding=0),
-                        nn.Sigmoid()))
-                else:
-                    self.reduc.add_module('plane_params', torch.nn.Conv2d(num_in_filters, out_channels=3, bias=False,
-                                                                          kernel_size=1, stride=1, padding=0))
-                break
+        stack = nn.Sequential()
+        for cin, cout in ops.reduc_chain(num_in_filters, num_out_filters):     # widths halve until < 8 (bts.py:105-122)
+            if cout > 0:
+                stack.add_module('inter_{}_{}'.format(cin, cout),
+                                 nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.ELU()))
+            elif is_final:
+                stack.add_module('final', nn.Sequential(nn.Conv2d(cin, 1, kernel_size=1, bias=False), nn.Sigmoid()))
             else:
-                self.reduc.add_module('inter_{}_{}'.format(num_in_filters, num_out_filters),
-                                      torch.nn.Sequential(nn.Conv2d(in_channels=num_in_filters, out_channels=num_out_filters,
-                                                                    bias=False, kernel_size=1, stride=1, padding=0),
-                                                          nn.ELU()))
-            num_in_filters = num_out_filters
-            num_out_filters = num_out_filters // 2
+                stack.add_module('plane_params', nn.Conv2d(cin, 3, kernel_size=1, bias=False))
+        self.reduc = stack
         self._pack = None
         self._pack_key = None
 
@@ -250,7 +239,7 @@ class local_planar_guidance(nn.Module):
     """bts.py:138-173.  ``abs_min`` is kept as a device scalar (bts_main.py:484-486 reads it)."""
 
     def __init__(self, upratio):
-        super(local_planar_guidance, self).__init__()
+        super().__init__()
         self.upratio = float(upratio)
         self.abs_min = None
 
@@ -269,53 +258,40 @@ class bts(nn.Module):
     """bts.py:175-293.  Same attribute names / state_dict; forward runs NHWC on HIP end to end."""
 
     def __init__(self, params, feat_out_channels, num_features=512):
-        super(bts, self).__init__()
+        super().__init__()
         self.params = params
-        self.feat_out_channels = list(feat_out_channels)
-        self.num_features = num_features
+        self.feat_out_channels = f = list(feat_out_channels)
+        self.num_features = nf = num_features
+        md = params.max_depth
 
-        self.upconv5 = upconv(feat_out_channels[4], num_features)
-        self.bn5 = nn.BatchNorm2d(num_features, momentum=0.01, affine=True, eps=1.1e-5)
+        def bn(c):
+            return nn.BatchNorm2d(c, eps=1.1e-5, momentum=0.01)
 
-        self.conv5 = torch.nn.Sequential(nn.Conv2d(num_features + feat_out_channels[3], num_features, 3, 1, 1, bias=False),
-                                         nn.ELU())
-        self.upconv4 = upconv(num_features, num_features // 2)
-        self.bn4 = nn.BatchNorm2d(num_features // 2, momentum=0.01, affine=True, eps=1.1e-5)
-        self.conv4 = torch.nn.Sequential(nn.Conv2d(num_features // 2 + feat_out_channels[2], num_features // 2, 3, 1, 1, bias=False),
-                                         nn.ELU())
-        self.bn4_2 = nn.BatchNorm2d(num_features // 2, momentum=0.01, affine=True, eps=1.1e-5)
+        def conv_elu(cin, cout):
+            return nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1, bias=False), nn.ELU())
 
-        self.daspp_3 = atrous_conv(num_features // 2, num_features // 4, 3, apply_bn_first=False)
-        self.daspp_6 = atrous_conv(num_features // 2 + num_features // 4 + feat_out_channels[2], num_features // 4, 6)
-        self.daspp_12 = atrous_conv(num_features + feat_out_channels[2], num_features // 4, 12)
-        self.daspp_18 = atrous_conv(num_features + num_features // 4 + feat_out_channels[2], num_features // 4, 18)
-        self.daspp_24 = atrous_conv(num_features + num_features // 2 + feat_out_channels[2], num_features // 4, 24)
-        self.daspp_conv = torch.nn.Sequential(nn.Conv2d(num_features + num_features // 2 + num_features // 4, num_features // 4, 3, 1, 1, bias=False),
-                                              nn.ELU())
-        self.reduc8x8 = reduction_1x1(num_features // 4, num_features // 4, self.params.max_depth)
-        self.lpg8x8 = local_planar_guidance(8)
-
-        self.upconv3 = upconv(num_features // 4, num_features // 4)
-        self.bn3 = nn.BatchNorm2d(num_features // 4, momentum=0.01, affine=True, eps=1.1e-5)
-        self.conv3 = torch.nn.Sequential(nn.Conv2d(num_features // 4 + feat_out_channels[1] + 1, num_features // 4, 3, 1, 1, bias=False),
-                                         nn.ELU())
-        self.reduc4x4 = reduction_1x1(num_features // 4, num_features // 8, self.params.max_depth)
-        self.lpg4x4 = local_planar_guidance(4)
-
-        self.upconv2 = upconv(num_features // 4, num_features // 8)
-        self.bn2 = nn.BatchNorm2d(num_features // 8, momentum=0.01, affine=True, eps=1.1e-5)
-        self.conv2 = torch.nn.Sequential(nn.Conv2d(num_features // 8 + feat_out_channels[0] + 1, num_features // 8, 3, 1, 1, bias=False),
-                                         nn.ELU())
-
-        self.reduc2x2 = reduction_1x1(num_features // 8, num_features // 16, self.params.max_depth)
-        self.lpg2x2 = local_planar_guidance(2)
-
-        self.upconv1 = upconv(num_features // 8, num_features // 16)
-        self.reduc1x1 = reduction_1x1(num_features // 16, num_features // 32, self.params.max_depth, is_final=True)
-        self.conv1 = torch.nn.Sequential(nn.Conv2d(num_features // 16 + 4, num_features // 16, 3, 1, 1, bias=False),
-                                         nn.ELU())
-        self.get_depth = torch.nn.Sequential(nn.Conv2d(num_features // 16, 1, 3, 1, 1, bias=False),
-                                             nn.Sigmoid())
+        cat4 = nf // 2 + f[2]                       # channels of concat4 = [upconv4 | skip2]
+        q = nf // 4                                 # ASPP branch width
+        # (attribute name, module): registration order == state_dict order of the reference decoder (bts.py:180-221)
+        plan = [
+            ("upconv5", upconv(f[4], nf)), ("bn5", bn(nf)), ("conv5", conv_elu(nf + f[3], nf)),
+            ("upconv4", upconv(nf, nf // 2)), ("bn4", bn(nf // 2)), ("conv4", conv_elu(cat4, nf // 2)), ("bn4_2", bn(nf // 2)),
+            ("daspp_3", atrous_conv(nf // 2, q, 3, apply_bn_first=False)),
+            ("daspp_6", atrous_conv(cat4 + 1 * q, q, 6)), ("daspp_12", atrous_conv(cat4 + 2 * q, q, 12)),
+            ("daspp_18", atrous_conv(cat4 + 3 * q, q, 18)), ("daspp_24", atrous_conv(cat4 + 4 * q, q, 24)),
+            ("daspp_conv", conv_elu(nf // 2 + 5 * q, q)),
+            ("reduc8x8", reduction_1x1(q, q, md)), ("lpg8x8", local_planar_guidance(8)),
+            ("upconv3", upconv(q, q)), ("bn3", bn(q)), ("conv3", conv_elu(q + f[1] + 1, q)),
+            ("reduc4x4", reduction_1x1(q, nf // 8, md)), ("lpg4x4", local_planar_guidance(4)),
+            ("upconv2", upconv(q, nf // 8)), ("bn2", bn(nf // 8)), ("conv2", conv_elu(nf // 8 + f[0] + 1, nf // 8)),
+            ("reduc2x2", reduction_1x1(nf // 8, nf // 16, md)), ("lpg2x2", local_planar_guidance(2)),
+            ("upconv1", upconv(nf // 8, nf // 16)),
+            ("reduc1x1", reduction_1x1(nf // 16, nf // 32, md, is_final=True)),
+            ("conv1", conv_elu(nf // 16 + 4, nf // 16)),
+            ("get_depth", nn.Sequential(nn.Conv2d(nf // 16, 1, 3, 1, 1, bias=False), nn.Sigmoid())),
+        ]
+        for name, module in plan:
+            setattr(self, name, module)
         self._pack = None
         self._pack_key = None
         self._bufs: Dict[tuple, Dict[str, torch.Tensor]] = {}
@@ -518,29 +494,30 @@ class encoder(nn.Module):
     """bts.py:295-338.  Same ``base_model`` tree / tap names; weights come from the checkpoint
     (``pretrained=True`` needs the network and torchvision, neither available here)."""
 
+    TAPS = {  # encoder name -> (module-name fragments that are tapped, channels of the five taps), bts.py:300-323
+        'densenet121_bts': (('relu0', 'pool0', 'transition1', 'transition2', 'norm5'), [64, 64, 128, 256, 1024]),
+        'densenet161_bts': (('relu0', 'pool0', 'transition1', 'transition2', 'norm5'), [96, 96, 192, 384, 2208]),
+    }
+    RESNET_TAPS = (('relu', 'layer1', 'layer2', 'layer3', 'layer4'), [64, 256, 512, 1024, 2048])
+
     def __init__(self, params):
-        super(encoder, self).__init__()
+        super().__init__()
         self.params = params
         self.base_model = build_base_model(params.encoder)
-        if 'densenet' in params.encoder:
-            self.feat_names = ['relu0', 'pool0', 'transition1', 'transition2', 'norm5']
-            self.feat_out_channels = {'densenet121_bts': [64, 64, 128, 256, 1024],
-                                      'densenet161_bts': [96, 96, 192, 384, 2208]}[params.encoder]
-        else:
-            self.feat_names = ['relu', 'layer1', 'layer2', 'layer3', 'layer4']
-            self.feat_out_channels = [64, 256, 512, 1024, 2048]
+        names, channels = self.TAPS.get(params.encoder, self.RESNET_TAPS)
+        self.feat_names, self.feat_out_channels = list(names), list(channels)
 
     def forward(self, x):
-        features = [x]
-        skip_feat = [x]
-        for k, v in self.base_model._modules.items():
-            if 'fc' in k or 'avgpool' in k:
+        """[x, tap@1/2, tap@1/4, tap@1/8, tap@1/16, tap@1/32]: run the backbone's children in order and keep the outputs
+        of those whose name contains a tap fragment (bts.py:327-338; 'fc'/'avgpool' children are skipped)."""
+        taps, cur = [x], x
+        for child_name, child in self.base_model.named_children():
+            if 'fc' in child_name or 'avgpool' in child_name:
                 continue
-            feature = v(features[-1])
-            features.append(feature)
-            if any(x in k for x in self.feat_names):
-                skip_feat.append(feature)
-        return skip_feat
+            cur = child(cur)
+            if any(fragment in child_name for fragment in self.feat_names):
+                taps.append(cur)
+        return taps
 
 
 class BtsModel(nn.Module):
