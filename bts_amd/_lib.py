@@ -15,6 +15,7 @@ SYMBOLS = (
     "bts_hip_abi_version", "bts_hip_error_string", "bts_lpg_fwd_f32", "bts_lpg_bwd_f32", "bts_lpg_fused_fwd_f32",
     "bts_reduc_fwd_f32", "bts_conv_fwd_f32", "bts_nchw_to_nhwc_f32", "bts_nhwc_to_nchw_f32",
     "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32", "bts_maxpool3x3s2_nhwc_f32", "bts_bn_relu_avgpool2_nhwc_f32",
+    "bts_conv_wgrad_f32",
 )
 
 ABI_VERSION = 1
@@ -33,6 +34,17 @@ class ConvDesc(C.Structure):
         ("y", C.c_void_p), ("y_pix_stride", C.c_long), ("y_nchw", C.c_int),
         ("subpixel", C.c_int), ("y2", C.c_void_p), ("y2_pix_stride", C.c_long),
         ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_long),
+    ]
+
+
+class ConvWgradDesc(C.Structure):
+    """struct bts_conv_wgrad_desc (include/bts_hip.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("x_pix_stride", C.c_long), ("c_in", C.c_int),
+        ("dy", C.c_void_p), ("dy_pix_stride", C.c_long), ("c_out", C.c_int),
+        ("B", C.c_int), ("h_in", C.c_int), ("w_in", C.c_int),
+        ("up", C.c_int), ("ksize", C.c_int), ("dil", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+        ("dw", C.c_void_p), ("ws", C.c_void_p), ("ws_floats", C.c_long),
     ]
 
 
@@ -71,6 +83,8 @@ def load():
     lib.bts_reduc_fwd_f32.argtypes = [vp, l, l, i, i, vp, l, f, i, i, vp, vp]
     lib.bts_conv_fwd_f32.restype = i
     lib.bts_conv_fwd_f32.argtypes = [C.POINTER(ConvDesc), vp]
+    lib.bts_conv_wgrad_f32.restype = i
+    lib.bts_conv_wgrad_f32.argtypes = [C.POINTER(ConvWgradDesc), vp]
     lib.bts_conv_plan_f32.restype = i
     lib.bts_conv_plan_f32.argtypes = [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.bts_nchw_to_nhwc_f32.restype = i

@@ -23,7 +23,7 @@ from typing import Dict, Tuple
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, train
 from ._lib import BtsHipError
 from .encoders import build_base_model
 
@@ -86,13 +86,6 @@ def _param_key(module: nn.Module):
     return tuple((t.data_ptr(), t._version, str(t.device)) for t in list(module.parameters()) + list(module.buffers()))
 
 
-def _require_eval(m: nn.Module, what: str):
-    if m.training:
-        raise NotImplementedError(
-            "bts_amd.%s: only the eval-mode (inference) forward is built on HIP; call .eval() first. "
-            "Training (batch-stat BN + backward) is the next row of SURVEY.md section 8(f)." % what)
-
-
 def _nhwc_in(x: torch.Tensor, c_pad_to: int = 4) -> Tuple[torch.Tensor, int, int, int, int]:
     """NCHW module-boundary tensor -> [npix, C_ld] NHWC buffer (zero pad channels)."""
     ops._need(x, "forward")
@@ -145,7 +138,8 @@ class atrous_conv(nn.Sequential):
         ops.conv_forward(mid2d, B, h, w, p["w2"], p["c_out"], 3, dil=self.dilation, y2d=y2d, tag="aspp")
 
     def forward(self, x):
-        _require_eval(self, "atrous_conv")
+        if self.training:
+            return train.atrous_forward(self, x)          # batch-statistic BN + autograd graph (bts_amd/train.py)
         xin, B, C, h, w = _nhwc_in(x)
         p = self.packed()
         if C % 4:
@@ -181,6 +175,8 @@ class upconv(nn.Module):
     def forward(self, x):
         if self.ratio not in (1, 2):
             raise BtsHipError("upconv: ratio %r not built (1 or 2)" % (self.ratio,))
+        if self.training:
+            return train.upconv_forward(self, x)
         xin, B, C, h, w = _nhwc_in(x)
         wp, cop, kp = self.packed()
         cout = self.conv.out_channels
@@ -225,6 +221,8 @@ class reduction_1x1(nn.Sequential):
                                normalize, out)
 
     def forward(self, net):
+        if self.training:
+            return train.reduction_forward(self, net)
         xin, B, C, h, w = _nhwc_in(net)
         if self.is_final:
             out = torch.empty((B, 1, h, w), dtype=torch.float32, device=net.device)
@@ -369,7 +367,6 @@ class bts(nn.Module):
 
     def forward(self, features, focal):
         """bts.forward(features, focal), bts.py:223-293: NCHW encoder taps in, the reference's 6-tuple out."""
-        _require_eval(self, "bts")
         if len(features) != 6:
             raise BtsHipError("bts.forward: expected the encoder's 6-element tap list, got %d" % len(features))
         skip0, skip1, skip2, skip3, dense = features[1], features[2], features[3], features[4], features[5]
@@ -386,6 +383,8 @@ class bts(nn.Module):
                                   "channels %s as in bts.py:300-323)" % (i + 1, tuple(t.shape), want, f))
         if focal is not None and self.params.dataset == 'kitti' and focal.numel() != B:
             raise BtsHipError("bts.forward: focal must have one entry per frame (%d), got %d" % (B, focal.numel()))
+        if self.training:
+            return train.decoder_forward(self, features, focal.to(dense.device) if isinstance(focal, torch.Tensor) else focal)
         ws = self._workspace(B, H, W, dense.device)
         # boundary: NCHW encoder taps -> NHWC channel slices (dense_features = ReLU(features[5]), bts.py:225)
         ops.nchw_to_nhwc(dense, ws["f5"][:, :f[4]], relu=True)
@@ -553,6 +552,9 @@ class BtsModel(nn.Module):
         return dec.forward_nhwc(ws, B, H, W, focal, r["dense"], r["norm5"], True, outs=outs)
 
     def forward(self, x, focal):
+        if self.training and self.native_encoder and 'densenet' in self.encoder.params.encoder \
+                and isinstance(x, torch.Tensor) and x.is_cuda:
+            return self.decoder(train.densenet_encoder_forward(self.encoder, x), focal)    # training step on HIP convs
         if not self._native_ok(x):
             skip_feat = self.encoder(x)
             return self.decoder(skip_feat, focal)

@@ -166,3 +166,12 @@ def focal_values(B: int, dataset: str = "kitti", seed: int = 1234) -> np.ndarray
 def image_batch(B: int, H: int, W: int, seed: int = 1234) -> np.ndarray:
     rng = np.random.Generator(np.random.PCG64(seed))
     return rng.standard_normal(size=(B, 3, H, W), dtype=np.float32)
+
+
+def train_targets(B: int, H: int, W: int, max_depth: float, seed: int):
+    """Synthetic ground-truth depth [B,1,H,W] in (0.5, max_depth) and a ~70 % validity mask for training-step
+    tests and goldens (the reference masks invalid lidar pixels, bts_main.py:478-481)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    gt = rng.uniform(0.5, max_depth, size=(B, 1, H, W)).astype(np.float32)
+    mask = rng.uniform(size=(B, 1, H, W)) > 0.3
+    return gt, mask

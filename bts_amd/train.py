@@ -1,0 +1,231 @@
+"""Training-step graph of the BTS decoder (reference: bts.forward in train() mode,
+pytorch/bts.py:223-293, driven by bts_main.py:476-500).
+
+Every convolution of the path -- forward, input gradient and weight gradient -- runs on the hand-written gfx950
+kernels of libbts_hip.so:
+
+* forward      : bts_conv_fwd_f32 (the inference kernel, plain epilogue),
+* input grad   : the same kernel on the output gradient with flipped/transposed weights
+                 (a stride-1 convolution's adjoint is a convolution: pad' = dil*(k-1) - pad),
+* weight grad  : bts_conv_wgrad_f32 (K = pixels GEMM with a deterministic split over pixels),
+* LPG          : bts_lpg_fwd_f32 / bts_lpg_bwd_f32 through ops.LpgFunction.
+
+What is cheap and memory-bound (batch-statistic BN, ELU/ReLU/sigmoid, sin/cos of the plane parameters, concat,
+normalize) stays on PyTorch-ROCm's precompiled elementwise/reduction kernels, kept in channels_last so the HIP
+convolutions read and write them in place as NHWC.  MIOpen is bypassed (no gfx950 find-db in this image).
+
+There is no CPU path here: non-CUDA tensors raise.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import BtsHipError
+
+_WS: Dict[Tuple[str, int], torch.Tensor] = {}
+WGRAD_WS_FLOATS = 48 << 20        # 192 MB of split-K partials per (device, stream)
+
+
+def _workspace(device: torch.device) -> torch.Tensor:
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = _WS[key] = torch.empty(WGRAD_WS_FLOATS, dtype=torch.float32, device=device)
+    return ws
+
+
+def _nhwc_rows(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """[B,C,H,W] (any strides) -> ([B*H*W, C4] contiguous NHWC rows with C padded to a multiple of 4, C4).
+    A channels_last tensor with C % 4 == 0 is viewed, not copied."""
+    B, C, H, W = x.shape
+    rows = x.permute(0, 2, 3, 1)
+    c4 = ops.round_up(C, 4)
+    if c4 != C:
+        rows = F.pad(rows, (0, c4 - C))
+    return rows.contiguous().view(B * H * W, c4), c4
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = conv2d(nearest_up(x, up), w, stride, padding, dilation), bias-free, on libbts_hip.so."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding, dilation, up, tag):
+        ops._need(x, "train.conv2d")
+        ops._need(weight, "train.conv2d")
+        B, C, h, w = x.shape
+        cout, cin, k, k2 = weight.shape
+        if cin != C or k != k2:
+            raise BtsHipError("train.conv2d: weight %s does not fit input %s" % (tuple(weight.shape), tuple(x.shape)))
+        x2d, c4 = _nhwc_rows(x.detach())
+        wp, _, _ = ops.pack_conv_weight(weight.detach(), c_in_ld=c4)
+        H = (h * up + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+        W = (w * up + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+        y = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+        ops.conv_forward(x2d, B, h, w, wp, cout, k, dil=dilation, up=up, c_in_ld=c4, y2d=y.view(B * H * W, cout),
+                         stride=stride, pad=padding, tag=tag + ".fwd", c_in_real=C)
+        ctx.save_for_backward(x2d, weight)
+        ctx.geom = (B, C, h, w, c4, cout, k, stride, padding, dilation, up, H, W, tag)
+        return y.permute(0, 3, 1, 2)          # [B,cout,H,W] channels_last view
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x2d, weight = ctx.saved_tensors
+        B, C, h, w, c4, cout, k, stride, padding, dilation, up, H, W, tag = ctx.geom
+        dy2d, co4 = _nhwc_rows(grad_out)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            pad_t = dilation * (k - 1) - padding
+            if stride != 1 or pad_t < 0:
+                raise BtsHipError("train.conv2d: input gradient is built for stride-1 convolutions with "
+                                  "padding <= dilation*(k-1) (every convolution of the BTS decoder and DenseNet "
+                                  "body); got stride %d padding %d" % (stride, padding))
+            w_t = weight.detach().flip(2, 3).transpose(0, 1)            # [cin, cout, k, k]
+            wp, _, _ = ops.pack_conv_weight(w_t, c_in_ld=co4)
+            Hs, Ws = h * up, w * up
+            dxu = torch.empty((B, Hs, Ws, C), dtype=torch.float32, device=grad_out.device)
+            ops.conv_forward(dy2d, B, H, W, wp, C, k, dil=dilation, c_in_ld=co4, y2d=dxu.view(B * Hs * Ws, C),
+                             pad=pad_t, tag=tag + ".dgrad", c_in_real=cout)
+            if up == 2:                                                 # adjoint of the nearest-2x upsample
+                dxu = dxu.view(B, h, 2, w, 2, C).sum(dim=(2, 4))
+            dx = dxu.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            g = ops.conv_wgrad(x2d, B, h, w, c4, dy2d, co4, k, dil=dilation, stride=stride, pad=padding, up=up,
+                               ws=_workspace(grad_out.device), tag=tag + ".wgrad")
+            dw = g[:cout, :, :C].reshape(cout, k, k, C).permute(0, 3, 1, 2)
+        return dx, dw, None, None, None, None, None
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, padding: int = 0, dilation: int = 1, stride: int = 1,
+           up: int = 1, tag: str = "conv") -> torch.Tensor:
+    """Differentiable bias-free convolution on the HIP kernels; ``up=2`` folds a nearest-2x upsample of ``x`` into
+    the gather (reference upconv, bts.py:90-92).  Returns a channels_last [B,c_out,H,W] tensor."""
+    return _ConvFn.apply(x, weight, stride, padding, dilation, up, tag)
+
+
+def _bn(x: torch.Tensor, bn: torch.nn.BatchNorm2d) -> torch.Tensor:
+    """nn.BatchNorm2d in train() mode on ATen's native kernels (MIOpen bypassed)."""
+    with torch.backends.cudnn.flags(enabled=False):
+        return bn(x)
+
+
+# ------------------------------------------------------------------------------------------ module forwards
+def atrous_forward(m, x):
+    """atrous_conv.forward, bts.py:79-80."""
+    seq = m.atrous_conv.aconv_sequence
+    if m.apply_bn_first:
+        x = _bn(x, m.atrous_conv.first_bn)
+    x = conv2d(F.relu(x), seq[1].weight, tag="aspp1x1")
+    x = F.relu(_bn(x, seq[2]))
+    return conv2d(x, seq[4].weight, padding=m.dilation, dilation=m.dilation, tag="aspp3x3")
+
+
+def upconv_forward(m, x):
+    """upconv.forward, bts.py:90-94."""
+    if m.ratio not in (1, 2):
+        raise BtsHipError("upconv: ratio %r not built (1 or 2)" % (m.ratio,))
+    return F.elu(conv2d(x, m.conv.weight, padding=1, up=int(m.ratio), tag="upconv"))
+
+
+def reduction_forward(m, net):
+    """reduction_1x1.forward, bts.py:124-136: the 1x1 stack, then (non-final) the plane-parameter transform."""
+    for layer in m.reduc:
+        if isinstance(layer, torch.nn.Conv2d):                       # plane_params
+            net = conv2d(net, layer.weight, tag="reduc")
+        else:
+            net = layer[1](conv2d(net, layer[0].weight, tag="reduc"))   # ELU (inter_*) or Sigmoid (final)
+    if m.is_final:
+        return net
+    import math
+    theta = torch.sigmoid(net[:, 0]) * (math.pi / 3)
+    phi = torch.sigmoid(net[:, 1]) * (math.pi * 2)
+    dist = torch.sigmoid(net[:, 2]) * m.max_depth
+    sin_t = torch.sin(theta)
+    return torch.stack([sin_t * torch.cos(phi), sin_t * torch.sin(phi), torch.cos(theta), dist], dim=1)
+
+
+def _conv_elu(seq, x, tag):
+    return F.elu(conv2d(x, seq[0].weight, padding=1, tag=tag))
+
+
+def decoder_forward(dec, features, focal):
+    """bts.forward in train() mode (bts.py:223-293): same dataflow as the inference path, as an autograd graph."""
+    skip0, skip1, skip2, skip3 = features[1], features[2], features[3], features[4]
+    md = dec.params.max_depth
+    cl = torch.channels_last
+    x = F.relu(features[5]).contiguous(memory_format=cl)
+    x = _bn(upconv_forward(dec.upconv5, x), dec.bn5)
+    iconv5 = _conv_elu(dec.conv5, torch.cat([x, skip3], 1), "conv5")
+    x = _bn(upconv_forward(dec.upconv4, iconv5), dec.bn4)
+    concat4 = torch.cat([x, skip2], 1)
+    iconv4 = _bn(_conv_elu(dec.conv4, concat4, "conv4"), dec.bn4_2)
+
+    grown, branches, inp = concat4, [], iconv4
+    for name in ("daspp_3", "daspp_6", "daspp_12", "daspp_18", "daspp_24"):
+        d = atrous_forward(getattr(dec, name), inp)
+        branches.append(d)
+        grown = torch.cat([grown, d], 1)
+        inp = grown
+    daspp_feat = _conv_elu(dec.daspp_conv, torch.cat([iconv4] + branches, 1), "daspp_conv")
+
+    def lpg_scale(reduc_mod, lpg_mod, feat):
+        r = reduction_forward(reduc_mod, feat)
+        plane_eq = torch.cat([F.normalize(r[:, :3], 2, 1), r[:, 3:4]], 1).contiguous()
+        return lpg_mod(plane_eq, focal).unsqueeze(1) / md
+
+    depth_8x8 = lpg_scale(dec.reduc8x8, dec.lpg8x8, daspp_feat)
+    x = _bn(upconv_forward(dec.upconv3, daspp_feat), dec.bn3)
+    iconv3 = _conv_elu(dec.conv3, torch.cat([x, skip1, depth_8x8[:, :, ::4, ::4]], 1), "conv3")
+    depth_4x4 = lpg_scale(dec.reduc4x4, dec.lpg4x4, iconv3)
+    x = _bn(upconv_forward(dec.upconv2, iconv3), dec.bn2)
+    iconv2 = _conv_elu(dec.conv2, torch.cat([x, skip0, depth_4x4[:, :, ::2, ::2]], 1), "conv2")
+    depth_2x2 = lpg_scale(dec.reduc2x2, dec.lpg2x2, iconv2)
+    upconv1 = upconv_forward(dec.upconv1, iconv2)
+    reduc1x1 = reduction_forward(dec.reduc1x1, upconv1)
+    iconv1 = _conv_elu(dec.conv1, torch.cat([upconv1, reduc1x1, depth_2x2, depth_4x4, depth_8x8], 1), "conv1")
+    final_depth = md * torch.sigmoid(conv2d(iconv1, dec.get_depth[0].weight, padding=1, tag="get_depth"))
+    if dec.params.dataset == 'kitti':
+        final_depth = final_depth * focal.view(-1, 1, 1, 1).float() / 715.0873
+    return depth_8x8, depth_4x4, depth_2x2, reduc1x1, final_depth, iconv1
+
+
+# ------------------------------------------------------------------------------------------ encoder (DenseNet)
+def _run_child(child, x):
+    """One module of a torchvision-layout DenseNet on the HIP convolutions (bias-free, ungrouped), batch-statistic
+    BN on ATen; ReLU and the pools are the modules themselves."""
+    nn = torch.nn
+    if isinstance(child, nn.Conv2d):
+        if child.bias is not None or child.groups != 1 or child.kernel_size[0] != child.kernel_size[1]:
+            raise BtsHipError("train: convolution %r is not built (bias-free, ungrouped, square only)" % (child,))
+        return conv2d(x, child.weight, padding=child.padding[0], dilation=child.dilation[0], stride=child.stride[0],
+                      tag="enc")
+    if isinstance(child, nn.BatchNorm2d):
+        return _bn(x, child)
+    if isinstance(child, nn.ModuleDict):                 # _DenseBlock: each layer sees the concat of all earlier ones
+        feats = [x]
+        for layer in child.values():
+            y = torch.cat(feats, 1) if len(feats) > 1 else feats[0]
+            for sub in layer.children():                 # norm1 relu1 conv1 norm2 relu2 conv2
+                y = _run_child(sub, y)
+            feats.append(y)
+        return torch.cat(feats, 1)
+    if isinstance(child, nn.Sequential):                 # _Transition
+        for sub in child:
+            x = _run_child(sub, x)
+        return x
+    return child(x)
+
+
+def densenet_encoder_forward(enc, x):
+    """encoder.forward (bts.py:327-338) for the DenseNet encoders in train() mode: same tap list, convolutions and
+    their gradients on libbts_hip.so."""
+    ops._need(x, "train.encoder")
+    taps, cur = [x], x.float().contiguous(memory_format=torch.channels_last)
+    for name, child in enc.base_model.named_children():
+        cur = _run_child(child, cur)
+        if any(fragment in name for fragment in enc.feat_names):
+            taps.append(cur)
+    return taps

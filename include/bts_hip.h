@@ -147,6 +147,34 @@ int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);
 int bts_conv_plan_f32(const bts_conv_desc* desc, int* bm, int* bn);
 
 /* ------------------------------------------------------------------------------------------
+ * Training step (reference: autograd of the nn.Conv2d modules of pytorch/bts.py:70-77, 87-93, 108-119,
+ * 180-221, driven by bts_main.py:476-500).  The input gradient of a stride-1 convolution IS a convolution
+ * (flipped, transposed weights; pad' = dil*(ksize-1) - pad) and goes through bts_conv_fwd_f32; the weight
+ * gradient is this entry point:
+ *
+ *   dw[co][tap][ci] = sum_p dy[p][co] * x[q(p,tap)][ci]        (q as in bts_conv_desc, incl. `up`)
+ *
+ * dw is written in OHWI order ([c_out][ksize*ksize][c_in], the layout the forward kernel packs from); the caller
+ * permutes to the state dict's OIHW.  c_in % 4 == 0 and c_out % 4 == 0 (pad odd channel counts with zeros).
+ * ws: optional scratch for the deterministic split over pixels; without it one workgroup column walks all pixels.
+ */
+typedef struct bts_conv_wgrad_desc {
+    const float* x;         /* forward input, NHWC: pixel q channel c at x[q*x_pix_stride + c]           */
+    long  x_pix_stride;
+    int   c_in;
+    const float* dy;        /* gradient of the forward output, NHWC [B,H,W,c_out]                        */
+    long  dy_pix_stride;
+    int   c_out;
+    int   B, h_in, w_in;    /* forward input size before the optional upsample                           */
+    int   up, ksize, dil, stride, pad;
+    float* dw;              /* [c_out][ksize*ksize][c_in]                                                */
+    float* ws;              /* NULL or scratch, exclusive to this stream while the call runs             */
+    long  ws_floats;
+} bts_conv_wgrad_desc;
+
+int bts_conv_wgrad_f32(const bts_conv_wgrad_desc* desc, bts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Layout movers between the NCHW boundary (pytorch/bts.py:347-349 tensors) and the NHWC
  * interior.  dst/src NHWC element (p,c) lives at base[p*pix_stride + c].
  *   relu != 0 applies max(v,0) on the way (bts.py:225: dense_features = ReLU(features[5])).

@@ -99,24 +99,26 @@ def reduction_forward(x: Tensor, weights: Sequence[Tensor], max_depth: float,
 
 
 # ------------------------------------------------------------------------- ASPP
-def _bn_eval(x: Tensor, p: Dict[str, Tensor], prefix: str, eps: float) -> Tensor:
+def _bn_eval(x: Tensor, p: Dict[str, Tensor], prefix: str, eps: float, training: bool = False) -> Tensor:
+    """nn.BatchNorm2d(momentum=0.01): running statistics in eval mode; with ``training`` the batch statistics
+    (and the running buffers in ``p`` are updated in place, as module.train() does)."""
     return F.batch_norm(x, p[prefix + ".running_mean"], p[prefix + ".running_var"],
-                        p[prefix + ".weight"], p[prefix + ".bias"], False, 0.01, eps)
+                        p[prefix + ".weight"], p[prefix + ".bias"], training, 0.01, eps)
 
 
 def atrous_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, dilation: int,
-                   apply_bn_first: bool) -> Tensor:
-    """atrous_conv.forward, bts.py:65-80 (eval-mode BN).
+                   apply_bn_first: bool, training: bool = False) -> Tensor:
+    """atrous_conv.forward, bts.py:65-80 (eval-mode BN unless ``training``).
 
     [first_bn eps 1.1e-5] -> ReLU -> conv1x1 -> BN(eps 1e-5) -> ReLU -> conv3x3 dilated.
     ``p`` maps '<prefix>.atrous_conv.*' keys to tensors.
     """
     a = prefix + ".atrous_conv"
     if apply_bn_first:
-        x = _bn_eval(x, p, a + ".first_bn", 1.1e-5)
+        x = _bn_eval(x, p, a + ".first_bn", 1.1e-5, training)
     x = F.relu(x)
     x = F.conv2d(x, p[a + ".aconv_sequence.1.weight"])
-    x = _bn_eval(x, p, a + ".aconv_sequence.2", 1e-5)
+    x = _bn_eval(x, p, a + ".aconv_sequence.2", 1e-5, training)
     x = F.relu(x)
     return F.conv2d(x, p[a + ".aconv_sequence.4.weight"], padding=dilation, dilation=dilation)
 
@@ -137,8 +139,9 @@ def _reduc_weights(p: Dict[str, Tensor], name: str) -> List[Tensor]:
 
 def decoder_forward(p: Dict[str, Tensor], features: Sequence[Optional[Tensor]], focal: Tensor,
                     max_depth: float, dataset: str,
-                    want_intermediates: bool = False):
-    """bts.forward, bts.py:223-293 (eval mode).  ``p``: decoder state dict (no prefix).
+                    want_intermediates: bool = False, training: bool = False):
+    """bts.forward, bts.py:223-293 (eval mode; ``training`` = module.train(): batch-statistic BN, autograd
+    through every op when the tensors in ``p`` / ``features`` require grad).  ``p``: decoder state dict (no prefix).
 
     Returns the reference's 6-tuple; with ``want_intermediates`` also a dict of
     named internals used by per-kernel parity tests.
@@ -146,25 +149,25 @@ def decoder_forward(p: Dict[str, Tensor], features: Sequence[Optional[Tensor]], 
     skip0, skip1, skip2, skip3 = features[1], features[2], features[3], features[4]
     dense_features = F.relu(features[5])
     upconv5 = upconv_forward(dense_features, p["upconv5.conv.weight"])
-    upconv5 = _bn_eval(upconv5, p, "bn5", 1.1e-5)
+    upconv5 = _bn_eval(upconv5, p, "bn5", 1.1e-5, training)
     concat5 = torch.cat([upconv5, skip3], dim=1)
     iconv5 = F.elu(F.conv2d(concat5, p["conv5.0.weight"], padding=1))
 
     upconv4 = upconv_forward(iconv5, p["upconv4.conv.weight"])
-    upconv4 = _bn_eval(upconv4, p, "bn4", 1.1e-5)
+    upconv4 = _bn_eval(upconv4, p, "bn4", 1.1e-5, training)
     concat4 = torch.cat([upconv4, skip2], dim=1)
     iconv4 = F.elu(F.conv2d(concat4, p["conv4.0.weight"], padding=1))
-    iconv4 = _bn_eval(iconv4, p, "bn4_2", 1.1e-5)
+    iconv4 = _bn_eval(iconv4, p, "bn4_2", 1.1e-5, training)
 
-    daspp_3 = atrous_forward(iconv4, p, "daspp_3", 3, False)
+    daspp_3 = atrous_forward(iconv4, p, "daspp_3", 3, False, training)
     concat4_2 = torch.cat([concat4, daspp_3], dim=1)
-    daspp_6 = atrous_forward(concat4_2, p, "daspp_6", 6, True)
+    daspp_6 = atrous_forward(concat4_2, p, "daspp_6", 6, True, training)
     concat4_3 = torch.cat([concat4_2, daspp_6], dim=1)
-    daspp_12 = atrous_forward(concat4_3, p, "daspp_12", 12, True)
+    daspp_12 = atrous_forward(concat4_3, p, "daspp_12", 12, True, training)
     concat4_4 = torch.cat([concat4_3, daspp_12], dim=1)
-    daspp_18 = atrous_forward(concat4_4, p, "daspp_18", 18, True)
+    daspp_18 = atrous_forward(concat4_4, p, "daspp_18", 18, True, training)
     concat4_5 = torch.cat([concat4_4, daspp_18], dim=1)
-    daspp_24 = atrous_forward(concat4_5, p, "daspp_24", 24, True)
+    daspp_24 = atrous_forward(concat4_5, p, "daspp_24", 24, True, training)
     concat4_daspp = torch.cat([iconv4, daspp_3, daspp_6, daspp_12, daspp_18, daspp_24], dim=1)
     daspp_feat = F.elu(F.conv2d(concat4_daspp, p["daspp_conv.0.weight"], padding=1))
 
@@ -180,7 +183,7 @@ def decoder_forward(p: Dict[str, Tensor], features: Sequence[Optional[Tensor]], 
     depth_8x8_scaled_ds = F.interpolate(depth_8x8_scaled, scale_factor=0.25, mode="nearest")
 
     upconv3 = upconv_forward(daspp_feat, p["upconv3.conv.weight"])
-    upconv3 = _bn_eval(upconv3, p, "bn3", 1.1e-5)
+    upconv3 = _bn_eval(upconv3, p, "bn3", 1.1e-5, training)
     concat3 = torch.cat([upconv3, skip1, depth_8x8_scaled_ds], dim=1)
     iconv3 = F.elu(F.conv2d(concat3, p["conv3.0.weight"], padding=1))
 
@@ -189,7 +192,7 @@ def decoder_forward(p: Dict[str, Tensor], features: Sequence[Optional[Tensor]], 
     depth_4x4_scaled_ds = F.interpolate(depth_4x4_scaled, scale_factor=0.5, mode="nearest")
 
     upconv2 = upconv_forward(iconv3, p["upconv2.conv.weight"])
-    upconv2 = _bn_eval(upconv2, p, "bn2", 1.1e-5)
+    upconv2 = _bn_eval(upconv2, p, "bn2", 1.1e-5, training)
     concat2 = torch.cat([upconv2, skip0, depth_4x4_scaled_ds], dim=1)
     iconv2 = F.elu(F.conv2d(concat2, p["conv2.0.weight"], padding=1))
 
@@ -214,6 +217,12 @@ def decoder_forward(p: Dict[str, Tensor], features: Sequence[Optional[Tensor]], 
                  plane_eq_2x2=plane_eq_2x2, upconv1=upconv1,
                  abs_min_8x8=am8, abs_min_4x4=am4, abs_min_2x2=am2)
     return outs, inter
+
+
+def silog_loss(depth_est: Tensor, depth_gt: Tensor, mask: Tensor, variance_focus: float) -> Tensor:
+    """silog_loss.forward, bts.py:41-48: d = log(est[mask]) - log(gt[mask]); sqrt(mean(d^2) - vf*mean(d)^2) * 10."""
+    d = torch.log(depth_est[mask]) - torch.log(depth_gt[mask])
+    return torch.sqrt((d ** 2).mean() - variance_focus * (d.mean() ** 2)) * 10.0
 
 
 def state_from_numpy(state_np) -> Dict[str, Tensor]:

@@ -181,7 +181,52 @@ def decoder_full():
     return out
 
 
+# ------------------------------------------------- (4) training step (batch-stat BN + backward)
+TRAIN_GRAD_SAMPLES = 64
+
+
+def decoder_train():
+    """Reference decoder in train() mode: forward with batch-statistic BN, silog loss on final_depth
+    (bts_main.py:476-481 protocol, variance_focus 0.85), backward.  Records the loss, the gradient w.r.t. the
+    encoder taps (full), per-parameter gradient norms + seeded samples, and the BN running stats after the step."""
+    out = {}
+    cname, B, H, W = "K", 2, 64, 96
+    enc, max_depth, dataset, _, _ = CONFIGS[cname]
+    feat = synth.ENCODER_CHANNELS[enc]
+    state = synth.decoder_state(feat, 512, seed=0)
+    dec = load_state(ref.bts(Params(enc, 512, max_depth, dataset), feat, 512), state).train()
+    feats = [t(f).requires_grad_(True) for f in synth.encoder_features(feat, B, H, W, seed=4321)[1:]]
+    focal = t(synth.focal_values(B, dataset, seed=4321))
+    gt, mask = synth.train_targets(B, H, W, max_depth, seed=77)
+    outs = dec([None] + feats, focal)
+    loss = ref.silog_loss(variance_focus=0.85)(outs[4], t(gt), t(mask))
+    loss.backward()
+    out["loss"] = np.asarray(loss.item(), dtype=np.float64)
+    for n, o in zip(OUT_NAMES, outs):
+        out["out_" + n] = o.detach().numpy()
+    for i, f in enumerate(feats):
+        out["grad_feat%d" % (i + 1)] = f.grad.numpy()
+    rng = np.random.Generator(np.random.PCG64(555))
+    for name, prm in dec.named_parameters():
+        g = prm.grad.detach().numpy().reshape(-1)
+        idx = np.sort(rng.choice(g.size, size=min(TRAIN_GRAD_SAMPLES, g.size), replace=False)).astype(np.int64)
+        out["gidx_" + name] = idx
+        out["gval_" + name] = g[idx]
+        out["gnorm_" + name] = np.asarray(np.sqrt((g.astype(np.float64) ** 2).sum()))
+    for name, buf in dec.named_buffers():
+        if name.endswith("running_mean") or name.endswith("running_var"):
+            out["buf_" + name] = buf.detach().numpy()
+    out["abs_min"] = np.asarray([dec.lpg8x8.abs_min.item(), dec.lpg4x4.abs_min.item(), dec.lpg2x2.abs_min.item()],
+                                dtype=np.float32)
+    return out
+
+
 def main():
+    if "--only-train" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "decoder_train.npz"), **decoder_train())
+        print("decoder_train.npz", os.path.getsize(os.path.join(HERE, "decoder_train.npz")) // 1024, "KiB")
+        return
+    np.savez_compressed(os.path.join(HERE, "decoder_train.npz"), **decoder_train())
     np.savez_compressed(os.path.join(HERE, "lpg_tables.npz"), **lpg_cases())
     np.savez_compressed(os.path.join(HERE, "modules_small.npz"), **module_cases())
     np.savez_compressed(os.path.join(HERE, "decoder_small.npz"), **decoder_small())

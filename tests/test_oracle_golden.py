@@ -143,3 +143,15 @@ def test_c_oracle_lpg_tables(golden_dir, k):
         lib.lpg_oracle_fwd(x.ctypes.data_as(fp), B, h, w, k, out.ctypes.data_as(fp), am.ctypes.data_as(fp))
         _eq(out, g["%s_%d_out" % (name, k)])
         assert am[0] == g["%s_%d_absmin" % (name, k)]
+
+
+def test_decoder_train_step(golden_dir):
+    """Training step (batch-stat BN, silog loss, backward) of the oracle vs the reference's own, recorded in
+    decoder_train.npz by tests/golden/gen_golden.py (reference bts.py in train() mode + bts.silog_loss)."""
+    from parity_util import check_train_against_golden, oracle_train_step
+    g = np.load(os.path.join(golden_dir, "decoder_train.npz"))
+    r = oracle_train_step()
+    bufs = {k: v for k, v in r["state"].items() if k.endswith(("running_mean", "running_var"))}
+    check_train_against_golden(g, r["loss"], [o.numpy() for o in r["outs"]], [f.numpy() for f in r["feat_grads"]],
+                               {k: v.numpy() for k, v in r["param_grads"].items()},
+                               {k: v.detach().numpy() for k, v in bufs.items()}, rtol_grad=1e-4, what="oracle")

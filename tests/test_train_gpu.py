@@ -1,0 +1,197 @@
+"""Training step on the HIP kernels: convolution input/weight gradients vs torch
+autograd on the CPU, the decoder's train()-mode step vs the reference-generated golden (decoder_train.npz) and the
+CPU oracle, and one whole-model step (DenseNet encoder + decoder)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bts_amd import synth
+from oracle import bts_oracle as O
+from parity_util import (CONFIGS, TRAIN_CASE, Params, assert_grads_close, check_train_against_golden, grad_error_report,
+                         make_inputs, oracle_train_step, t)
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_conv(x, w, stride, padding, dilation, up):
+    if up == 2:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    return F.conv2d(x, w, stride=stride, padding=padding, dilation=dilation)
+
+
+CONV_CASES = [
+    # B, cin, cout, h, w, k, dil, pad, stride, up, x_needs_grad
+    (2, 128, 128, 9, 13, 1, 1, 0, 1, 1, True),        # reduc / aspp 1x1
+    (2, 256, 128, 11, 19, 3, 3, 3, 1, 1, True),       # daspp_3
+    (1, 64, 32, 13, 17, 3, 24, 24, 1, 1, True),       # dilation larger than the map
+    (2, 225, 128, 10, 14, 3, 1, 1, 1, 1, True),       # conv3: odd channel count
+    (2, 8, 3, 16, 24, 1, 1, 0, 1, 1, True),           # plane_params
+    (2, 8, 1, 16, 24, 1, 1, 0, 1, 1, True),           # final
+    (2, 36, 32, 12, 20, 3, 1, 1, 1, 1, True),         # conv1
+    (2, 48, 40, 6, 9, 3, 1, 1, 1, 2, True),           # upconv: nearest-2x folded in
+    (2, 3, 96, 32, 48, 7, 1, 3, 2, 1, False),         # densenet conv0 (stride 2; the image needs no gradient)
+    (3, 192, 48, 7, 11, 3, 1, 1, 1, 1, True),         # densenet growth conv
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_gradients_vs_torch_cpu(case):
+    from bts_amd import train
+    B, cin, cout, h, w, k, dil, pad, stride, up, xg = case
+    gen = torch.Generator().manual_seed(hash(case) % (1 << 31))
+    x = torch.randn(B, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, k, k, generator=gen) / np.sqrt(cin * k * k)
+    x64, w64 = x.double().requires_grad_(xg), wt.double().requires_grad_(True)
+    y_ref = _ref_conv(x64, w64, stride, pad, dil, up)
+    gy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(gy.double())
+    xd, wd = x.cuda().requires_grad_(xg), wt.cuda().requires_grad_(True)
+    y = train.conv2d(xd, wd, padding=pad, dilation=dil, stride=stride, up=up)
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    y.backward(gy.cuda())
+    torch.cuda.synchronize()
+
+    def close(got, ref, what):
+        ref = ref.float()
+        scale = ref.abs().max().item()
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 2e-5 * scale * np.sqrt(max(1, ref.numel() // ref.shape[0] // 64)) + 1e-6, (what, err, scale)
+
+    close(y.detach(), y_ref.detach(), "forward")
+    close(wd.grad, w64.grad, "weight grad")
+    if xg:
+        close(xd.grad, x64.grad, "input grad")
+
+
+def test_wgrad_split_is_deterministic_and_matches_unsplit():
+    """The pixel split only regroups a sum: with and without workspace agree to fp32 rounding, and two runs of the
+    split path are bit-identical (fixed-order reduction, no atomics)."""
+    from bts_amd import ops
+    B, h, w, cin, cout = 4, 44, 76, 64, 32
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B * h * w, cin, generator=gen).cuda()
+    dy = torch.randn(B * h * w, cout, generator=gen).cuda()
+    ws = torch.empty(8 << 20, device="cuda")
+    a = ops.conv_wgrad(x, B, h, w, cin, dy, cout, 3, ws=ws)
+    b = ops.conv_wgrad(x, B, h, w, cin, dy, cout, 3, ws=ws)
+    c = ops.conv_wgrad(x, B, h, w, cin, dy, cout, 3, ws=None)
+    assert torch.equal(a, b)
+    assert (a - c).abs().max().item() <= 1e-4 * c.abs().max().item()
+
+
+def _train_decoder(device="cuda"):
+    from bts_amd import bts as M
+    c = TRAIN_CASE
+    enc, md, ds, _, _ = CONFIGS[c["cname"]]
+    feat = synth.ENCODER_CHANNELS[enc]
+    dec = M.bts(Params(enc, 512, md, ds), feat, 512)
+    sd = {k: (torch.tensor(v) if np.ndim(v) == 0 else t(v)) for k, v in synth.decoder_state(feat, 512, 0).items()}
+    dec.load_state_dict(sd, strict=True)
+    return dec.train().to(device)
+
+
+def test_decoder_train_step_vs_golden_and_oracle(golden_dir):
+    """bts.forward in train() mode + silog loss + backward on the GPU == the reference's own training step."""
+    from bts_amd import bts as M
+    c = TRAIN_CASE
+    _, md, ds, _, _ = CONFIGS[c["cname"]]
+    g = np.load(os.path.join(golden_dir, "decoder_train.npz"))
+    dec = _train_decoder()
+    feats, focal = make_inputs(c["cname"], c["B"], c["H"], c["W"], c["feat_seed"])
+    feats = [None] + [f.cuda().requires_grad_(True) for f in feats[1:]]
+    gt, mask = synth.train_targets(c["B"], c["H"], c["W"], md, c["target_seed"])
+    outs = dec(feats, focal.cuda())
+    loss = M.silog_loss(variance_focus=c["variance_focus"])(outs[4], t(gt).cuda(), t(mask).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    pg = {n: p.grad.cpu().numpy() for n, p in dec.named_parameters()}
+    bufs = {n: b.cpu().numpy() for n, b in dec.named_buffers() if n.endswith(("running_mean", "running_var"))}
+    check_train_against_golden(g, loss.item(), [o.detach().cpu().numpy() for o in outs],
+                               [f.grad.cpu().numpy() for f in feats[1:]], pg, bufs, what="hip/golden", robust=True)
+    np.testing.assert_allclose([dec.lpg8x8.abs_min.item(), dec.lpg4x4.abs_min.item(), dec.lpg2x2.abs_min.item()],
+                               g["abs_min"], rtol=1e-3, atol=1e-6)
+    # every element of every gradient against the oracle in fp64 (the exact-arithmetic yardstick), with the fp32 CPU
+    # oracle's own distance to it printed beside ours
+    r64, r32 = oracle_train_step(torch.float64), oracle_train_step()
+    ref = {n: v.numpy() for n, v in r64["param_grads"].items()}
+    per, l2 = grad_error_report(pg, ref)
+    per32, l2_32 = grad_error_report({n: v.numpy() for n, v in r32["param_grads"].items()}, ref)
+    print("global rel-L2 vs fp64: hip %.2e, cpu fp32 oracle %.2e; worst tensor hip %.2e, cpu fp32 %.2e"
+          % (l2, l2_32, max(per.values()), max(per32.values())))
+    assert_grads_close(per, l2, "hip/fp64 oracle", fp32_floor=(per32, l2_32))
+
+
+def test_train_mode_modules_match_oracle():
+    """Module-level train() forwards (atrous_conv with batch-stat BN, reduction_1x1, upconv) vs the oracle."""
+    from bts_amd import bts as M
+    torch.manual_seed(5)
+    x = torch.randn(2, 64, 11, 19)
+    m = M.atrous_conv(64, 32, 6).train()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * 0.2 + (1.0 if p.dim() == 1 else 0.0))
+    p = {"d.atrous_conv." + k: v.detach().clone() for k, v in m.atrous_conv.state_dict().items()}
+    ref = O.atrous_forward(x, p, "d", 6, True, training=True)
+    got = m.cuda()(x.cuda())
+    assert (got.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    np.testing.assert_allclose(m.atrous_conv.first_bn.running_mean.cpu().numpy(),
+                               p["d.atrous_conv.first_bn.running_mean"].numpy(), rtol=1e-4, atol=1e-6)
+    r = M.reduction_1x1(64, 32, 80.0).train()
+    ws = [mm.weight.detach().clone() for mm in r.reduc.modules() if isinstance(mm, torch.nn.Conv2d)]
+    ref = O.reduction_forward(x, ws, 80.0, False)
+    got = r.cuda()(x.cuda())
+    assert (got.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    u = M.upconv(64, 16).train()
+    ref = O.upconv_forward(x, u.conv.weight.detach())
+    got = u.cuda()(x.cuda())
+    assert (got.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_btsmodel_train_step_densenet121_vs_cpu():
+    """One whole-model training step (bts_main.py:476-500 protocol): DenseNet121 encoder + decoder, silog loss,
+    backward.  CPU side: the same torch encoder modules + the oracle decoder with autograd, in fp64 (yardstick) and
+    fp32 (the noise floor fp32 arithmetic itself has on this step, see parity_util.fp32_noise_floor)."""
+    import copy
+    from bts_amd import bts as M
+    params = Params("densenet121_bts", 512, 80.0, "kitti")
+    torch.manual_seed(21)
+    model = M.BtsModel(params).train()
+    B, H, W = 2, 64, 96
+    x = torch.from_numpy(synth.image_batch(B, H, W, 5))
+    focal = torch.from_numpy(synth.focal_values(B, "kitti", 5))
+    gt, mask = synth.train_targets(B, H, W, 80.0, 9)
+
+    def cpu_step(dtype):
+        enc = copy.deepcopy(model.encoder).to(dtype)
+        state = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone())
+                 for k, v in model.decoder.state_dict().items()}
+        for k, v in state.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        outs = O.decoder_forward(state, enc(x.to(dtype)), focal.to(dtype), 80.0, "kitti", training=True)
+        loss = O.silog_loss(outs[4], t(gt).to(dtype), t(mask), 0.85)
+        loss.backward()
+        grads = {"encoder." + n: p.grad for n, p in enc.named_parameters()}
+        grads.update({"decoder." + n: v.grad for n, v in state.items() if v.requires_grad})
+        return loss.item(), grads
+
+    loss64, g64 = cpu_step(torch.float64)
+    loss32, g32 = cpu_step(torch.float32)
+    mg = model.cuda()
+    outs = mg(x.cuda(), focal.cuda())
+    loss = M.silog_loss(0.85)(outs[4], t(gt).cuda(), t(mask).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss64) <= max(2e-4 * abs(loss64), 4 * abs(loss32 - loss64)), (loss.item(), loss64, loss32)
+    got = {n: p.grad.cpu().numpy() for n, p in mg.named_parameters()}
+    ref = {n: v.numpy() for n, v in g64.items()}
+    per, l2 = grad_error_report(got, ref)
+    per32, l2_32 = grad_error_report({n: v.numpy() for n, v in g32.items()}, ref)
+    print("whole-model step, global rel-L2 vs fp64: hip %.2e, cpu fp32 %.2e; worst tensor hip %.2e, cpu fp32 %.2e"
+          % (l2, l2_32, max(per.values()), max(per32.values())))
+    assert_grads_close(per, l2, "whole model / fp64", fp32_floor=(per32, l2_32))
+    checked = len(per)
+    assert checked > 400
