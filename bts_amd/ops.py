@@ -461,6 +461,67 @@ def conv_wgrad(x2d: torch.Tensor, B: int, h_in: int, w_in: int, c_in: int, dy2d:
     return dw
 
 
+# ------------------------------------------------------------------------------ train-mode BN
+def bn_train_ws_floats(npix: int, C: int) -> int:
+    return int(_lib.load().bts_bn_train_ws_floats(npix, C))
+
+
+def bn_train_stats(x2d: torch.Tensor, C: int, gamma, beta, eps: float, momentum: float, running_mean, running_var,
+                   ws: torch.Tensor):
+    """Batch statistics of NHWC rows (bts_bn_train_stats_f32): returns (mean, invstd, scale, shift), each [C];
+    running_mean / running_var (or None) are updated in place."""
+    xs, xc = _rows2d(x2d, "bn_train_stats")
+    if C % 4 or C > xc:
+        raise BtsHipError("bn_train_stats: C must be a multiple of 4 within the view (%d/%d)" % (C, xc))
+    out = torch.empty((4, C), dtype=torch.float32, device=x2d.device)
+    _need(ws, "bn_train_stats")
+    npix = x2d.shape[0]
+    with torch.cuda.device(x2d.device):
+        rc = _launch("bn_stats_kernel", "bn.stats", 3.0 * npix * C, 4.0 * npix * C,
+                     lambda: _lib.load().bts_bn_train_stats_f32(
+                         x2d.data_ptr(), xs, npix, C, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+                         _ptr(running_mean), _ptr(running_var), ws.data_ptr(), ws.numel(), out[0].data_ptr(),
+                         out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream(x2d)))
+    _lib.check(rc, "bts_bn_train_stats_f32")
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_apply(x2d: torch.Tensor, C: int, scale: torch.Tensor, shift: torch.Tensor, relu: bool, y2d: torch.Tensor):
+    """y = [relu](x*scale + shift) over NHWC rows (bts_bn_apply_nhwc_f32)."""
+    xs, _ = _rows2d(x2d, "bn_apply")
+    ys, _ = _rows2d(y2d, "bn_apply")
+    npix = x2d.shape[0]
+    with torch.cuda.device(x2d.device):
+        rc = _launch("bn_apply_kernel", "bn.apply", 2.0 * npix * C, 8.0 * npix * C,
+                     lambda: _lib.load().bts_bn_apply_nhwc_f32(x2d.data_ptr(), xs, npix, C, scale.data_ptr(),
+                                                               shift.data_ptr(), int(bool(relu)), y2d.data_ptr(), ys,
+                                                               _stream(x2d)))
+    _lib.check(rc, "bts_bn_apply_nhwc_f32")
+    return y2d
+
+
+def bn_train_backward(x2d: torch.Tensor, dy2d: torch.Tensor, C: int, mean, invstd, scale, shift, relu: bool,
+                      ws: torch.Tensor, dx2d: Optional[torch.Tensor]):
+    """Backward of batch-statistic BN (+ fused ReLU): returns (dgamma, dbeta); dx2d (or None) is filled in place."""
+    xs, _ = _rows2d(x2d, "bn_train_backward")
+    ds, _ = _rows2d(dy2d, "bn_train_backward")
+    npix = x2d.shape[0]
+    if dy2d.shape[0] != npix:
+        raise BtsHipError("bn_train_backward: gradient rows %d != input rows %d" % (dy2d.shape[0], npix))
+    g = torch.empty((2, C), dtype=torch.float32, device=x2d.device)
+    dxs = 0
+    if dx2d is not None:
+        dxs, _ = _rows2d(dx2d, "bn_train_backward")
+    with torch.cuda.device(x2d.device):
+        rc = _launch("bn_bwd_kernels", "bn.bwd", 10.0 * npix * C, 20.0 * npix * C,
+                     lambda: _lib.load().bts_bn_train_bwd_f32(
+                         x2d.data_ptr(), xs, dy2d.data_ptr(), ds, npix, C, mean.data_ptr(), invstd.data_ptr(),
+                         scale.data_ptr(), shift.data_ptr(), int(bool(relu)), ws.data_ptr(), ws.numel(),
+                         g[0].data_ptr(), g[1].data_ptr(), _ptr(dx2d), dxs, _stream(x2d)))
+    _lib.check(rc, "bts_bn_train_bwd_f32")
+    return g[0], g[1]
+
+
 # ------------------------------------------------------------------------------ tail
 def pack_planes(planes: Sequence[torch.Tensor], dst2d: torch.Tensor):
     """Interleave 1-channel maps ([B,1,H,W] contiguous each) into dst2d [npix, n] (an NHWC slice)."""

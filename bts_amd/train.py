@@ -106,20 +106,70 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, padding: int = 0, dilation: in
     return _ConvFn.apply(x, weight, stride, padding, dilation, up, tag)
 
 
-def _bn(x: torch.Tensor, bn: torch.nn.BatchNorm2d) -> torch.Tensor:
-    """nn.BatchNorm2d in train() mode on ATen's native kernels (MIOpen bypassed)."""
+_BN_WS: Dict[Tuple[str, int], torch.Tensor] = {}
+
+
+def _bn_workspace(device: torch.device, floats: int) -> torch.Tensor:
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _BN_WS.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = _BN_WS[key] = torch.empty(max(floats, 1 << 20), dtype=torch.float32, device=device)
+    return ws
+
+
+class _BnFn(torch.autograd.Function):
+    """y = [relu](batch_norm(x)) with batch statistics, on libbts_hip.so (bn_train.hip); the module's running
+    buffers are updated in place exactly as nn.BatchNorm2d.train() does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, relu):
+        B, C, H, W = x.shape
+        x2d, _ = _nhwc_rows(x.detach())
+        npix = B * H * W
+        ws = _bn_workspace(x.device, ops.bn_train_ws_floats(npix, C))
+        track = bn.track_running_stats and bn.running_mean is not None
+        mean, invstd, scale, shift = ops.bn_train_stats(
+            x2d, C, None if gamma is None else gamma.detach(), None if beta is None else beta.detach(), bn.eps,
+            bn.momentum, bn.running_mean if track else None, bn.running_var if track else None, ws)
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+        ops.bn_apply(x2d, C, scale, shift, relu, y.view(npix, C))
+        ctx.save_for_backward(x2d, mean, invstd, scale, shift)
+        ctx.meta = (B, C, H, W, relu, gamma is not None)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x2d, mean, invstd, scale, shift = ctx.saved_tensors
+        B, C, H, W, relu, affine = ctx.meta
+        dy2d, _ = _nhwc_rows(grad_out)
+        npix = B * H * W
+        dx = torch.empty((B, H, W, C), dtype=torch.float32, device=grad_out.device) if ctx.needs_input_grad[0] else None
+        ws = _bn_workspace(grad_out.device, ops.bn_train_ws_floats(npix, C))
+        dgamma, dbeta = ops.bn_train_backward(x2d, dy2d, C, mean, invstd, scale, shift, relu, ws,
+                                              None if dx is None else dx.view(npix, C))
+        return (None if dx is None else dx.permute(0, 3, 1, 2), dgamma if affine and ctx.needs_input_grad[1] else None,
+                dbeta if affine and ctx.needs_input_grad[2] else None, None, None)
+
+
+def _bn(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool = False) -> torch.Tensor:
+    """nn.BatchNorm2d (+ the ReLU that follows it) inside the training graph.  train() mode with a fixed momentum and
+    C % 4 == 0 runs on the HIP kernels; a frozen (eval-mode) layer or an exotic configuration runs on ATen's native
+    kernels (MIOpen bypassed: no gfx950 find-db in this image)."""
+    if bn.training and bn.momentum is not None and x.shape[1] % 4 == 0 and x.is_cuda and x.dtype == torch.float32:
+        return _BnFn.apply(x, bn.weight, bn.bias, bn, relu)
     with torch.backends.cudnn.flags(enabled=False):
-        return bn(x)
+        y = bn(x)
+    return F.relu(y) if relu else y
 
 
 # ------------------------------------------------------------------------------------------ module forwards
 def atrous_forward(m, x):
     """atrous_conv.forward, bts.py:79-80."""
     seq = m.atrous_conv.aconv_sequence
-    if m.apply_bn_first:
-        x = _bn(x, m.atrous_conv.first_bn)
-    x = conv2d(F.relu(x), seq[1].weight, tag="aspp1x1")
-    x = F.relu(_bn(x, seq[2]))
+    x = _bn(x, m.atrous_conv.first_bn, relu=True) if m.apply_bn_first else F.relu(x)
+    x = _bn(conv2d(x, seq[1].weight, tag="aspp1x1"), seq[2], relu=True)
     return conv2d(x, seq[4].weight, padding=m.dilation, dilation=m.dilation, tag="aspp3x3")
 
 
@@ -193,39 +243,49 @@ def decoder_forward(dec, features, focal):
 
 
 # ------------------------------------------------------------------------------------------ encoder (DenseNet)
-def _run_child(child, x):
-    """One module of a torchvision-layout DenseNet on the HIP convolutions (bias-free, ungrouped), batch-statistic
-    BN on ATen; ReLU and the pools are the modules themselves."""
+def _run_children(children, x, tapped=None, taps=None):
+    """Run (name, module) pairs in order on the HIP kernels: bias-free ungrouped convolutions, batch-statistic BN
+    with the ReLU that follows it fused in; pools and stray activations are the modules themselves.
+    ``tapped(name)``: children whose output joins ``taps`` (encoder.forward's skip list)."""
     nn = torch.nn
-    if isinstance(child, nn.Conv2d):
-        if child.bias is not None or child.groups != 1 or child.kernel_size[0] != child.kernel_size[1]:
-            raise BtsHipError("train: convolution %r is not built (bias-free, ungrouped, square only)" % (child,))
-        return conv2d(x, child.weight, padding=child.padding[0], dilation=child.dilation[0], stride=child.stride[0],
-                      tag="enc")
-    if isinstance(child, nn.BatchNorm2d):
-        return _bn(x, child)
-    if isinstance(child, nn.ModuleDict):                 # _DenseBlock: each layer sees the concat of all earlier ones
-        feats = [x]
-        for layer in child.values():
-            y = torch.cat(feats, 1) if len(feats) > 1 else feats[0]
-            for sub in layer.children():                 # norm1 relu1 conv1 norm2 relu2 conv2
-                y = _run_child(sub, y)
-            feats.append(y)
-        return torch.cat(feats, 1)
-    if isinstance(child, nn.Sequential):                 # _Transition
-        for sub in child:
-            x = _run_child(sub, x)
-        return x
-    return child(x)
+    i = 0
+    while i < len(children):
+        name, child = children[i]
+        last = name
+        if isinstance(child, nn.Conv2d):
+            if child.bias is not None or child.groups != 1 or child.kernel_size[0] != child.kernel_size[1]:
+                raise BtsHipError("train: convolution %r is not built (bias-free, ungrouped, square only)" % (child,))
+            x = conv2d(x, child.weight, padding=child.padding[0], dilation=child.dilation[0], stride=child.stride[0],
+                       tag="enc")
+        elif isinstance(child, nn.BatchNorm2d):
+            fuse = (i + 1 < len(children) and isinstance(children[i + 1][1], nn.ReLU)
+                    and not (tapped is not None and tapped(name)))
+            x = _bn(x, child, relu=fuse)
+            if fuse:
+                i += 1
+                last = children[i][0]
+        elif isinstance(child, nn.ModuleDict):               # _DenseBlock: each layer sees the concat of all earlier ones
+            feats = [x]
+            for layer in child.values():
+                y = torch.cat(feats, 1) if len(feats) > 1 else feats[0]
+                feats.append(_run_children(list(layer.named_children()), y))   # norm1 relu1 conv1 norm2 relu2 conv2
+            x = torch.cat(feats, 1)
+        elif isinstance(child, nn.Sequential):               # _Transition
+            x = _run_children(list(child.named_children()), x)
+        else:
+            x = child(x)
+        if tapped is not None and tapped(last):
+            taps.append(x)
+        i += 1
+    return x
 
 
 def densenet_encoder_forward(enc, x):
-    """encoder.forward (bts.py:327-338) for the DenseNet encoders in train() mode: same tap list, convolutions and
-    their gradients on libbts_hip.so."""
+    """encoder.forward (bts.py:327-338) for the DenseNet encoders in train() mode: same tap list, convolutions, norm
+    layers and their gradients on libbts_hip.so."""
     ops._need(x, "train.encoder")
-    taps, cur = [x], x.float().contiguous(memory_format=torch.channels_last)
-    for name, child in enc.base_model.named_children():
-        cur = _run_child(child, cur)
-        if any(fragment in name for fragment in enc.feat_names):
-            taps.append(cur)
+    taps = [x]
+    cur = x.float().contiguous(memory_format=torch.channels_last)
+    _run_children(list(enc.base_model.named_children()), cur,
+                  tapped=lambda name: any(fragment in name for fragment in enc.feat_names), taps=taps)
     return taps

@@ -174,6 +174,29 @@ typedef struct bts_conv_wgrad_desc {
 
 int bts_conv_wgrad_f32(const bts_conv_wgrad_desc* desc, bts_stream_t stream);
 
+/* Batch-statistic BatchNorm over NHWC rows [npix][C] (nn.BatchNorm2d in train() mode: pytorch/bts.py:69-76,
+ * 182-202 and the DenseNet norm layers), C % 4 == 0, row strides % 4 == 0 and >= C (channel slices work in place).
+ *
+ * bts_bn_train_stats_f32 : per-channel batch mean and biased variance (deterministic tree of Chan-merged partials)
+ *     -> mean, invstd = 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale; running_mean/var (may be
+ *     NULL) updated as PyTorch does: r = (1-momentum)*r + momentum*{mean | unbiased var}.  gamma/beta NULL = 1/0.
+ *     ws: scratch of bts_bn_train_ws_floats(npix, C) floats.
+ * bts_bn_apply_nhwc_f32  : y = [relu](x*scale + shift)   (relu != 0 fuses the ReLU that follows the norm layer)
+ * bts_bn_train_bwd_f32   : with dy' = dy masked by the fused ReLU (recomputed from x): dbeta = sum dy',
+ *     dgamma = sum dy'*xhat, dx = scale*(dy' - dbeta/n - xhat*dgamma/n)  (dx may be NULL: statistics only).
+ */
+long bts_bn_train_ws_floats(long npix, int C);
+int bts_bn_train_stats_f32(const float* x, long x_pix_stride, long npix, int C, const float* gamma,
+                           const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                           float* ws, long ws_floats, float* mean, float* invstd, float* scale, float* shift,
+                           bts_stream_t stream);
+int bts_bn_apply_nhwc_f32(const float* x, long x_pix_stride, long npix, int C, const float* scale,
+                          const float* shift, int relu, float* y, long y_pix_stride, bts_stream_t stream);
+int bts_bn_train_bwd_f32(const float* x, long x_pix_stride, const float* dy, long dy_pix_stride, long npix, int C,
+                         const float* mean, const float* invstd, const float* scale, const float* shift, int relu,
+                         float* ws, long ws_floats, float* dgamma, float* dbeta, float* dx, long dx_pix_stride,
+                         bts_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Layout movers between the NCHW boundary (pytorch/bts.py:347-349 tensors) and the NHWC
  * interior.  dst/src NHWC element (p,c) lives at base[p*pix_stride + c].

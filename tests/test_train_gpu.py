@@ -82,6 +82,50 @@ def test_wgrad_split_is_deterministic_and_matches_unsplit():
     assert (a - c).abs().max().item() <= 1e-4 * c.abs().max().item()
 
 
+@pytest.mark.parametrize("shape,relu", [((2, 48, 5, 7), True), ((3, 128, 9, 13), False), ((2, 2208, 2, 3), True),
+                                        ((4, 96, 64, 96), True), ((1, 256, 1, 2), False), ((2, 132, 16, 24), True),
+                                        ((2, 32, 33, 41), False), ((1, 64, 176, 352), True)])
+def test_bn_train_forward_backward_vs_torch(shape, relu):
+    """Batch-statistic BN (+fused ReLU) kernels vs F.batch_norm(training=True) in fp64 on the CPU: output, running
+    statistics (momentum 0.01, unbiased variance), and all three gradients; also on a channel slice of a wider
+    buffer (row stride > C), the way concat buffers hand their slices over."""
+    from bts_amd import train
+    B, C, H, W = shape
+    gen = torch.Generator().manual_seed(C * 131 + H)
+    wide = torch.randn(B, C + 8, H, W, generator=gen) * 1.7 + 0.4
+    x = wide[:, 4:4 + C]
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.1
+    rm, rv = torch.randn(C, generator=gen) * 0.1, torch.rand(C, generator=gen) + 0.5
+    x64, g64, b64 = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    y64 = F.batch_norm(x64, rm64, rv64, g64, b64, True, 0.01, 1.1e-5)
+    if relu:
+        y64 = F.relu(y64)
+    gy = torch.randn(shape, generator=gen)
+    y64.backward(gy.double())
+    bn = torch.nn.BatchNorm2d(C, eps=1.1e-5, momentum=0.01)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn = bn.cuda().train()
+    wide_d = wide.cuda().contiguous(memory_format=torch.channels_last)
+    xd = wide_d[:, 4:4 + C].detach().requires_grad_(True)
+    y = train._bn(xd, bn, relu=relu)
+    y.backward(gy.cuda())
+    torch.cuda.synchronize()
+
+    def close(got, ref, tol, what):
+        scale = max(ref.abs().max().item(), 1e-12)
+        err = (got.detach().cpu().double() - ref).abs().max().item()
+        assert err <= tol * scale, (what, err, scale)
+    close(y, y64.detach(), 2e-5, "forward")
+    close(bn.running_mean, rm64, 1e-5, "running_mean")
+    close(bn.running_var, rv64, 1e-5, "running_var")
+    assert int(bn.num_batches_tracked.item()) == 1
+    close(xd.grad, x64.grad, 2e-4, "dx")
+    close(bn.weight.grad, g64.grad, 2e-4, "dgamma")
+    close(bn.bias.grad, b64.grad, 2e-4, "dbeta")
+
+
 def _train_decoder(device="cuda"):
     from bts_amd import bts as M
     c = TRAIN_CASE
