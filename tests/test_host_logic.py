@@ -120,3 +120,31 @@ def test_pack_layouts():
     assert torch.equal(l3[16 * 1 + 0], w3[0, 4:8, 0, 0]) and l3[16 * 2 + 0].abs().sum() == 0      # k 8..15 are padding
     assert ops.reduc_chain(128, 128) == [(128, 128), (128, 64), (64, 32), (32, 16), (16, 8), (8, -1)]
     assert synth.reduc_chain_channels(32, 16, True) == [32, 16, 8, 1]
+
+
+def test_trainer_protocol_pieces():
+    """bts_main.py's model-side training protocol: poly LR decay (:420,:603), frozen-layer fragments (:165-182),
+    AdamW groups (:354-356), ground-truth mask thresholds (:551-553)."""
+    from collections import namedtuple
+    from bts_amd import bts as M, trainer
+    assert trainer.poly_lr(0, 1000, 1e-4) == pytest.approx(1e-4)
+    assert trainer.poly_lr(1000, 1000, 1e-4) == pytest.approx(1e-5)
+    assert trainer.poly_lr(500, 1000, 1e-4, 2e-5) == pytest.approx((1e-4 - 2e-5) * 0.5 ** 0.9 + 2e-5)
+    assert trainer.fixing_layers("densenet161_bts") == ['conv0', 'norm']
+    assert trainer.fixing_layers("resnext101_bts", fix_first_conv_blocks=True) == \
+        ['base_model.conv1', 'base_model.layer1.0', 'base_model.layer1.1', '.bn']
+    assert trainer.fixing_layers("densenet121_bts", fix_first_conv_block=True) == ['conv0', 'denseblock1.denselayer1', 'norm']
+    P = namedtuple("P", "encoder bts_size max_depth dataset")
+    model = M.BtsModel(P("densenet121_bts", 512, 80.0, "kitti"))
+    frozen = trainer.set_misc(model, "densenet121_bts")
+    names = dict(model.encoder.named_parameters())
+    assert "base_model.conv0.weight" in frozen and not names["base_model.conv0.weight"].requires_grad
+    assert all(("norm" in n or "conv0" in n) for n in frozen)
+    assert names["base_model.denseblock1.denselayer1.conv1.weight"].requires_grad
+    assert all(p.requires_grad for p in model.decoder.parameters())
+    opt = trainer.make_optimizer(model, 1e-4, 1e-2, 1e-3)
+    assert [g["weight_decay"] for g in opt.param_groups] == [1e-2, 0]
+    assert opt.param_groups[0]["eps"] == 1e-3
+    gt = torch.tensor([0.05, 0.5, 1.5])
+    assert trainer.gt_mask(gt, "kitti").tolist() == [False, False, True]
+    assert trainer.gt_mask(gt, "nyu").tolist() == [False, True, True]

@@ -239,3 +239,35 @@ def test_btsmodel_train_step_densenet121_vs_cpu():
     assert_grads_close(per, l2, "whole model / fp64", fp32_floor=(per32, l2_32))
     checked = len(per)
     assert checked > 400
+
+
+def test_trainer_steps_update_only_trainable_parameters():
+    """Three iterations of the bts_main.py protocol (set_misc freeze, AdamW groups, poly LR, silog on valid pixels):
+    frozen encoder layers stay bit-identical, everything else moves, running statistics advance, loss stays finite."""
+    from bts_amd import bts as M, trainer
+    params = Params("densenet121_bts", 512, 80.0, "kitti")
+    torch.manual_seed(3)
+    model = M.BtsModel(params).train().cuda()
+    frozen = set(trainer.set_misc(model, params.encoder))
+    opt = trainer.make_optimizer(model, 1e-4, 1e-2, 1e-3)
+    crit = M.silog_loss(0.85)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    B, H, W = 2, 64, 96
+    x = torch.from_numpy(synth.image_batch(B, H, W, 5)).cuda()
+    focal = torch.from_numpy(synth.focal_values(B, "kitti", 5)).cuda()
+    gt, _ = synth.train_targets(B, H, W, 80.0, 9)
+    gt = torch.from_numpy(gt).cuda()
+    losses = []
+    for step in range(3):
+        loss, outs = trainer.train_step(model, opt, crit, x, focal, gt, lr=trainer.poly_lr(step, 100, 1e-4))
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)), losses
+    assert len(outs) == 6 and tuple(outs[4].shape) == (B, 1, H, W)
+    for n, p in model.named_parameters():
+        same = torch.equal(p.detach(), before[n])
+        if n[len("encoder."):] in frozen:
+            assert same and p.grad is None, n
+        else:
+            assert not same, n
+    assert int(model.decoder.bn5.num_batches_tracked.item()) == 3
+    assert model.decoder.lpg8x8.abs_min is not None
