@@ -16,6 +16,7 @@ SYMBOLS = (
     "bts_reduc_fwd_f32", "bts_conv_fwd_f32", "bts_nchw_to_nhwc_f32", "bts_nhwc_to_nchw_f32",
     "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32", "bts_maxpool3x3s2_nhwc_f32", "bts_bn_relu_avgpool2_nhwc_f32",
     "bts_conv_wgrad_f32", "bts_bn_train_ws_floats", "bts_bn_train_stats_f32", "bts_bn_apply_nhwc_f32", "bts_bn_train_bwd_f32",
+    "bts_pack_weights_blocks", "bts_pack_weights_f32",
 )
 
 ABI_VERSION = 1
@@ -93,6 +94,10 @@ def load():
     lib.bts_bn_apply_nhwc_f32.argtypes = [vp, l, l, i, vp, vp, i, vp, l, vp]
     lib.bts_bn_train_bwd_f32.restype = i
     lib.bts_bn_train_bwd_f32.argtypes = [vp, l, vp, l, l, i, vp, vp, vp, vp, i, vp, l, vp, vp, vp, l, vp]
+    lib.bts_pack_weights_blocks.restype = l
+    lib.bts_pack_weights_blocks.argtypes = [l, l]
+    lib.bts_pack_weights_f32.restype = i
+    lib.bts_pack_weights_f32.argtypes = [vp, i, l, vp]
     lib.bts_conv_plan_f32.restype = i
     lib.bts_conv_plan_f32.argtypes = [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.bts_nchw_to_nhwc_f32.restype = i

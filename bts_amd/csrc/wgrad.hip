@@ -7,8 +7,9 @@
 // Both operands are K-major with their M/N index contiguous in memory -- exactly how NHWC stores them -- so a
 // tile row (one pixel) is loaded with coalesced 16-byte reads and lands in LDS as [k][m] / [k][n]; an MFMA operand
 // is then one conflict-free ds_read_b32 (lane l reads row 2*kk + (l>>5), column base + (l&31)).
-// K is the long axis (B*H*W up to 6.8 M pixels) and the output is small, so the launch always splits K over
-// gridDim.y; partials go to a workspace and are summed in a fixed order (deterministic, no atomics).
+// K is the long axis (B*H*W up to 6.8 M pixels) and the output is small, so the launch splits K over gridDim.y;
+// partials go to a workspace and are summed in a fixed order (deterministic, no atomics); plan_wgrad picks the tile
+// (128x128 / 64x128 / 32x128 / 64x64) and the split together.
 #include "common.h"
 #include <stdint.h>
 #include <stdlib.h>
@@ -31,7 +32,7 @@ struct WgradArgs {
 
 // One workgroup = 4 waves arranged WM x WN over a BM x BN tile of dw; each wave owns (BM/WM) x (BN/WN).
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
@@ -67,8 +68,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int n_it = k_begin < k_end ? (int)((k_end - k_begin + WBK - 1) / WBK) : 0;
     const unsigned HW = (unsigned)a.H * (unsigned)a.W;
 
-    f32x4 ra[PA], rb[PB];
-    auto issue = [&](int it) __attribute__((always_inline)) {
+    // Two staging register sets: the loads of tile it+2 are issued at the top of step it and consumed (written to LDS)
+    // at the bottom of step it+1, so every global load has two full MFMA steps to land.
+    f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+    int pb[PB], py[PB], px[PB];             // (frame, row, column) of each gathered row's output pixel at the next step
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const unsigned pix = k_begin + b_row + p * BROWS;
+        const unsigned b = pix / HW, rem = pix - b * HW;
+        pb[p] = (int)b;
+        py[p] = (int)(rem / (unsigned)a.W);
+        px[p] = (int)(rem - (unsigned)py[p] * (unsigned)a.W);
+    }
+    auto issue = [&](int it, f32x4 (&ra)[PA], f32x4 (&rb)[PB]) __attribute__((always_inline)) {
         const unsigned base = k_begin + (unsigned)it * WBK;
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
@@ -81,18 +93,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
             const unsigned pix = base + b_row + p * BROWS;
-            const unsigned pp = pix < k_end ? pix : k_begin;
-            const unsigned b = pp / HW, rem = pp - b * HW;
-            const unsigned y = rem / (unsigned)a.W, xq = rem - y * (unsigned)a.W;
-            const int iy = (int)y * a.stride + off_y, ix = (int)xq * a.stride + off_x;
+            const int iy = py[p] * a.stride + off_y, ix = px[p] * a.stride + off_x;
             const bool ok = b_ok && pix < k_end && iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws;
-            const int sy = ok ? (iy >> a.ups) : 0, sx = ok ? (ix >> a.ups) : 0;
-            const float* src = a.x + ((size_t)(b * a.h_in + sy) * a.w_in + sx) * a.x_pix_stride + ci;
+            const int sb = ok ? pb[p] : 0, sy = ok ? (iy >> a.ups) : 0, sx = ok ? (ix >> a.ups) : 0;
+            const float* src = a.x + ((size_t)(sb * a.h_in + sy) * a.w_in + sx) * a.x_pix_stride + ci;
             f32x4 v = *reinterpret_cast<const f32x4*>(src);
             rb[p] = ok ? v : (f32x4)(0.f);
+            // advance this row's output pixel by one K-step without dividing (issue() is called for it = 0, 1, 2, ...)
+            px[p] += WBK;
+            while (px[p] >= a.W) { px[p] -= a.W; ++py[p]; }
+            while (py[p] >= a.H) { py[p] -= a.H; ++pb[p]; }
         }
     };
-    auto stage = [&](int buf) __attribute__((always_inline)) {
+    auto stage = [&](int buf, const f32x4 (&ra)[PA], const f32x4 (&rb)[PB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < PA; ++p)
             *reinterpret_cast<f32x4*>(&As[(buf * WBK + a_row + p * AROWS) * BM + a_col]) = ra[p];
@@ -107,14 +120,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16)(0.f);
 
-    if (n_it > 0) {
-        issue(0);
-        stage(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < n_it; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < n_it) issue(it + 1);
+    auto mfma_step = [&](int cur) __attribute__((always_inline)) {
         const float* Ac = As + cur * WBK * BM + wm0 + l31;
         const float* Bc = Bs + cur * WBK * BN + wn0 + l31;
 #pragma unroll
@@ -129,7 +135,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma32x2(av[i], bv[j], acc[i][j]);
         }
-        if (it + 1 < n_it) stage(cur ^ 1);
+    };
+
+    if (n_it > 0) {
+        issue(0, ra0, rb0);
+        if (n_it > 1) issue(1, ra1, rb1);
+        stage(0, ra0, rb0);
+    }
+    __syncthreads();
+    for (int it = 0; it < n_it; it += 2) {
+        // even step: LDS[0] holds tile it, set 1 holds tile it+1, set 0 is free
+        if (it + 2 < n_it) issue(it + 2, ra0, rb0);
+        mfma_step(0);
+        if (it + 1 < n_it) stage(1, ra1, rb1);
+        __syncthreads();
+        if (it + 1 >= n_it) break;
+        // odd step: LDS[1] holds tile it+1, set 0 holds tile it+2, set 1 is free
+        if (it + 3 < n_it) issue(it + 3, ra1, rb1);
+        mfma_step(1);
+        if (it + 2 < n_it) stage(0, ra0, rb0);
         __syncthreads();
     }
 
@@ -148,33 +172,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         }
 }
 
+// Sum the ksplit partial tiles in a fixed order.  The output is small and the split count can be in the hundreds, so
+// the walk over splits is itself spread over 16 lanes per element (a serial walk is pure load latency): a block owns
+// 16 consecutive float4 elements, lane j adds splits j, j+16, ... (four independent loads in flight), then lane 0 adds
+// the 16 lane sums in order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            long count4, int ksplit) {
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < count4; t += (long)gridDim.x * blockDim.x) {
-        f32x4 v = reinterpret_cast<const f32x4*>(ws)[t];
-        for (int s = 1; s < ksplit; ++s) v += reinterpret_cast<const f32x4*>(ws)[(size_t)s * count4 + t];
-        reinterpret_cast<f32x4*>(dw)[t] = v;
+    const int el = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const long t = (long)blockIdx.x * 16 + el;
+    const long tt = t < count4 ? t : count4 - 1;
+    const f32x4* p = reinterpret_cast<const f32x4*>(ws) + tt;
+    f32x4 v = (f32x4)(0.f);
+    int s = lane;
+    for (; s + 48 < ksplit; s += 64) {
+        const f32x4 a0 = p[(size_t)s * count4], a1 = p[(size_t)(s + 16) * count4];
+        const f32x4 a2 = p[(size_t)(s + 32) * count4], a3 = p[(size_t)(s + 48) * count4];
+        v += (a0 + a1) + (a2 + a3);
+    }
+    for (; s < ksplit; s += 16) v += p[(size_t)s * count4];
+    __shared__ f32x4 red[16][16];
+    red[lane][el] = v;
+    __syncthreads();
+    if (lane == 0 && t < count4) {
+        f32x4 r = red[0][el];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) r += red[j][el];
+        reinterpret_cast<f32x4*>(dw)[t] = r;
     }
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_wgrad(WgradArgs a, float* dw, float* ws, long ws_floats, hipStream_t s) {
+int launch_wgrad(WgradArgs a, long split, float* dw, float* ws, hipStream_t s) {
     const int m_tiles = (a.c_out + BM - 1) / BM;
     a.n_ntiles = (a.N + BN - 1) / BN;
     const long tiles = (long)m_tiles * a.n_ntiles;
     const long per = (long)a.c_out * a.N;
-    // Split the pixel axis until ~4 workgroups per CU are in flight (256 CUs), keeping >= 8 K-steps per split and
-    // the partials within the caller's workspace.  A function of the geometry only, so results are reproducible.
-    static const long target = getenv("BTS_WGRAD_TARGET") ? atol(getenv("BTS_WGRAD_TARGET")) : 1024;
-    long split = (target + tiles - 1) / tiles;
-    const long max_by_k = ((long)a.M + 8 * WBK - 1) / (8 * WBK);
-    if (split > max_by_k) split = max_by_k;
-    if (split > 1024) split = 1024;
-    if (ws == nullptr || ws_floats < 2 * per) split = 1;
-    else if (split * per > ws_floats) split = ws_floats / per;
-    if (split < 1) split = 1;
     long pps = (((long)a.M + split - 1) / split + WBK - 1) / WBK * WBK;
-    split = ((long)a.M + pps - 1) / pps;
+    split = ((long)a.M + pps - 1) / pps;                         // no empty splits
     a.pix_per_split = (unsigned)pps;
     a.out = split > 1 ? ws : dw;
     const size_t lds_bytes = (size_t)2 * WBK * (BM + BN) * sizeof(float);
@@ -188,11 +222,46 @@ int launch_wgrad(WgradArgs a, float* dw, float* ws, long ws_floats, hipStream_t 
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)split), dim3(256), lds_bytes, s, a);
     if (split > 1) {
         const long count4 = per / 4;      // N % 4 == 0
-        long blocks = (count4 + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, dw, count4, (int)split);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count4 + 15) / 16)), dim3(256), 0, s, ws, dw, count4,
+                           (int)split);
     }
     return (int)hipGetLastError();
+}
+
+// Tile + split plan.  The output (c_out x taps*c_in) is small and the pixel axis long, so parallelism comes from
+// splitting pixels; every split costs one partial tile written and re-read.  Candidates are scored by
+//   useful fraction of the padded tile grid  x  per-tile efficiency  x  chip fill (workgroups / 512, capped at 1)
+//   x  operand bytes / (operand bytes + partial-tile bytes)
+// with the split chosen to reach ~768 workgroups within [>= 4 K-steps per split, <= 1024 splits, workspace size].
+struct WgradPlan { int variant; long split; };
+
+inline WgradPlan plan_wgrad(int c_out, int N, long M, long ws_floats, bool have_ws) {
+    static const int bm[4] = {128, 64, 32, 64}, bn[4] = {128, 128, 128, 64};
+    static const double eff[4] = {1.0, 0.9, 0.75, 0.8};
+    static const long target = getenv("BTS_WGRAD_TARGET") ? atol(getenv("BTS_WGRAD_TARGET")) : 768;
+    const long per = (long)c_out * N;
+    long max_split = M / (4 * WBK);
+    if (max_split > 1024) max_split = 1024;
+    if (!have_ws || ws_floats < 2 * per) max_split = 1;
+    else if (max_split * per > ws_floats) max_split = ws_floats / per;
+    if (max_split < 1) max_split = 1;
+    const double in_bytes = 4.0 * (double)M * (c_out + N);           // operands read once (taps re-read from cache)
+    WgradPlan best = {0, 1};
+    double best_score = -1.0;
+    for (int v = 0; v < 4; ++v) {
+        const long mt = (c_out + bm[v] - 1) / bm[v], nt = (N + bn[v] - 1) / bn[v];
+        const long tiles = mt * nt;
+        long split = (target + tiles - 1) / tiles;
+        if (split > max_split) split = max_split;
+        const double useful = (double)c_out * N / ((double)mt * bm[v] * nt * bn[v]);
+        double fill = (double)(tiles * split) / 512.0;
+        if (fill > 1.0) fill = 1.0;
+        const double partial_bytes = split > 1 ? 8.0 * (double)split * (double)per : 0.0;   // written once, read once
+        const double score = useful * eff[v] * fill * in_bytes / (in_bytes + partial_bytes);
+        if (score > best_score * 1.0001) { best_score = score; best = {v, split}; }
+    }
+    if (const char* f = getenv("BTS_WGRAD_VARIANT")) best.variant = atoi(f) & 3;
+    return best;
 }
 
 }  // namespace
@@ -227,7 +296,73 @@ extern "C" int bts_conv_wgrad_f32(const bts_conv_wgrad_desc* d, bts_stream_t str
     a.N = d->ksize * d->ksize * d->c_in;
     a.pix_per_split = 0; a.n_ntiles = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (d->c_out > 64) return launch_wgrad<128, 128, 2, 2>(a, d->dw, d->ws, d->ws_floats, s);
-    if (d->c_out > 32) return launch_wgrad<64, 128, 1, 4>(a, d->dw, d->ws, d->ws_floats, s);
-    return launch_wgrad<32, 128, 1, 4>(a, d->dw, d->ws, d->ws_floats, s);
+    const WgradPlan p = plan_wgrad(d->c_out, a.N, (long)a.M, d->ws_floats, d->ws != nullptr);
+    switch (p.variant) {
+        case 0: return launch_wgrad<128, 128, 2, 2>(a, p.split, d->dw, d->ws, s);
+        case 1: return launch_wgrad<64, 128, 1, 4>(a, p.split, d->dw, d->ws, s);
+        case 2: return launch_wgrad<32, 128, 1, 4>(a, p.split, d->dw, d->ws, s);
+        default: return launch_wgrad<64, 64, 2, 2>(a, p.split, d->dw, d->ws, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched weight packing for the training step: every step the optimiser rewrites the OIHW parameters, and both the
+// forward kernel ([c_out_pad][k_pad], K = tap*c_in_ld + c) and the input-gradient pass (the same layout of the
+// flipped, transposed kernel) need them re-laid.  One launch re-packs every registered weight from a device table.
+namespace {
+
+struct PackEntry {          // 12 x int64, filled by the host (bts_amd/train.py)
+    const float* src;       // OIHW parameter
+    float* dst;             // [rows_pad][k_pad]
+    long rows, inner;       // packed rows (c_out, or c_in for the transposed layout) and real inner channels
+    long k, c_in_ld, rows_pad, k_pad;
+    long s_row, s_c;        // element strides in src for the packed row / inner channel
+    long flip;              // 0: taps as stored, 1: spatially flipped (input gradient)
+    long first_block;       // prefix sum of blocks over the table
+};
+
+constexpr int PACK_PER_BLOCK = 256 * 4 * 4;
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __restrict__ table, int n) {
+    int lo = 0, hi = n - 1;                       // the entry whose block range holds blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_block <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackEntry e = table[lo];
+    const long total = e.rows_pad * e.k_pad;
+    const long base = ((long)blockIdx.x - e.first_block) * PACK_PER_BLOCK;
+    const long kk2 = e.k * e.k;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i0 = base + ((long)u * 256 + threadIdx.x) * 4;
+        if (i0 >= total) continue;
+        const long row = i0 / e.k_pad, col0 = i0 - row * e.k_pad;
+        f32x4 v = (f32x4)(0.f);
+        if (row < e.rows) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long col = col0 + j;
+                const long tap = col / e.c_in_ld, c = col - tap * e.c_in_ld;
+                if (tap < kk2 && c < e.inner) {
+                    const long t = e.flip ? kk2 - 1 - tap : tap;
+                    v[j] = e.src[row * e.s_row + c * e.s_c + t];
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(e.dst + i0) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" long bts_pack_weights_blocks(long rows_pad, long k_pad) {
+    return (rows_pad * k_pad + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK;
+}
+
+extern "C" int bts_pack_weights_f32(const void* table, int n_entries, long total_blocks, bts_stream_t stream) {
+    if (!table || n_entries <= 0 || total_blocks <= 0 || total_blocks > 2147483647L) return BTS_ERR_INVALID;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackEntry*)table, n_entries);
+    return (int)hipGetLastError();
 }

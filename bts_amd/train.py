@@ -18,6 +18,7 @@ There is no CPU path here: non-CUDA tensors raise.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -38,6 +39,19 @@ def _workspace(device: torch.device) -> torch.Tensor:
     return ws
 
 
+_SPLITK_WS: Dict[Tuple[str, int], torch.Tensor] = {}
+SPLITK_WS_FLOATS = 16 << 20       # 64 MB: lets the forward / input-gradient launches of the deep, pixel-starved layers
+                                  # split K (bts_conv_desc.splitk_ws); larger layers never split
+
+
+def _splitk_workspace(device: torch.device) -> torch.Tensor:
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = _SPLITK_WS[key] = torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)
+    return ws
+
+
 def _nhwc_rows(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
     """[B,C,H,W] (any strides) -> ([B*H*W, C4] contiguous NHWC rows with C padded to a multiple of 4, C4).
     A channels_last tensor with C % 4 == 0 is viewed, not copied."""
@@ -47,6 +61,96 @@ def _nhwc_rows(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
     if c4 != C:
         rows = F.pad(rows, (0, c4 - C))
     return rows.contiguous().view(B * H * W, c4), c4
+
+
+class WeightPacker:
+    """Packed copies of the convolution weights for the training step.
+
+    The optimiser rewrites the OIHW parameters every iteration; the HIP kernels want them as [c_out_pad][k_pad]
+    (forward) and as the same layout of the flipped, transposed kernel (input gradient).  Entries are registered on
+    first use; ``refresh()`` -- called at the top of each training forward -- re-packs every entry whose parameter
+    changed (``Tensor._version``) in ONE launch of bts_pack_weights_f32.  A stale entry met later is re-packed on the
+    spot, so correctness never depends on ``refresh`` having been called."""
+
+    FWD, DGRAD = 0, 1
+
+    def __init__(self):
+        self.entries = {}          # (data_ptr, shape, c_in_ld, mode) -> dict(weight, dst, version, geometry)
+        self._table = None
+        self._table_key = None
+
+    @staticmethod
+    def _geometry(weight, c_in_ld, mode):
+        cout, cin, k, _ = weight.shape
+        if mode == WeightPacker.FWD:
+            rows, inner, s_row, s_c, flip = cout, cin, cin * k * k, k * k, 0
+        else:
+            rows, inner, s_row, s_c, flip = cin, cout, k * k, cin * k * k, 1
+        rows_pad = ops.round_up(rows, 32)
+        k_pad = ops.round_up(k * k * c_in_ld, 32)
+        return rows, inner, k, c_in_ld, rows_pad, k_pad, s_row, s_c, flip
+
+    def _table_for(self, items):
+        import numpy as np
+        from . import _lib
+        lib = _lib.load()
+        rows, first = [], 0
+        for e in items:
+            g = e["geom"]
+            rows.append([e["ptr"], e["dst"].data_ptr(), g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], first])
+            first += int(lib.bts_pack_weights_blocks(g[4], g[5]))
+        return torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(items[0]["dst"].device), first
+
+    def _launch(self, items, table, blocks):
+        from . import _lib
+        dev = items[0]["dst"].device
+        with torch.cuda.device(dev):
+            rc = ops._launch("pack_weights_kernel", "pack", 0.0, 0.0,
+                             lambda: _lib.load().bts_pack_weights_f32(table.data_ptr(), len(items), blocks,
+                                                                      torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(rc, "bts_pack_weights_f32")
+        for e in items:
+            e["version"] = e["wref"]()._version
+
+    def get(self, weight, c_in_ld, mode):
+        """Packed buffer for ``weight`` (an nn.Parameter or any contiguous OIHW CUDA tensor), current with its values."""
+        key = (weight.data_ptr(), tuple(weight.shape), c_in_ld, mode)
+        e = self.entries.get(key)
+        if e is not None and e["wref"]() is None:          # the tensor this entry was packed from is gone: the address
+            e = None                                        # now belongs to someone else's values
+        if e is None:
+            if not weight.is_contiguous():
+                raise BtsHipError("train.conv2d: weight must be contiguous OIHW")
+            g = self._geometry(weight, c_in_ld, mode)
+            e = self.entries[key] = dict(wref=weakref.ref(weight), ptr=weight.data_ptr(), geom=g, version=-1,
+                                         dst=torch.empty((g[4], g[5]), dtype=torch.float32, device=weight.device))
+            self._table_key = None
+        if e["version"] != e["wref"]()._version:
+            table, blocks = self._table_for([e])
+            self._launch([e], table, blocks)
+        return e["dst"]
+
+    def refresh(self):
+        """Re-pack every registered weight whose parameter changed since its last packing, in one launch."""
+        dead = [k for k, e in self.entries.items() if e["wref"]() is None]
+        for k in dead:
+            del self.entries[k]
+        stale = [e for e in self.entries.values() if e["version"] != e["wref"]()._version]
+        if not stale:
+            return
+        key = tuple(id(e) for e in stale)
+        if self._table_key != key:                        # the usual case after step 1: the same full set every step
+            self._table, self._table_blocks = self._table_for(stale)
+            self._table_key = key
+        self._launch(stale, self._table, self._table_blocks)
+
+
+_PACKER = WeightPacker()
+
+
+def begin_step():
+    """Top of a training forward: bring all packed weights up to date with one launch."""
+    _PACKER.refresh()
 
 
 class _ConvFn(torch.autograd.Function):
@@ -61,19 +165,21 @@ class _ConvFn(torch.autograd.Function):
         if cin != C or k != k2:
             raise BtsHipError("train.conv2d: weight %s does not fit input %s" % (tuple(weight.shape), tuple(x.shape)))
         x2d, c4 = _nhwc_rows(x.detach())
-        wp, _, _ = ops.pack_conv_weight(weight.detach(), c_in_ld=c4)
+        wp = _PACKER.get(weight, c4, WeightPacker.FWD)
         H = (h * up + 2 * padding - dilation * (k - 1) - 1) // stride + 1
         W = (w * up + 2 * padding - dilation * (k - 1) - 1) // stride + 1
         y = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
         ops.conv_forward(x2d, B, h, w, wp, cout, k, dil=dilation, up=up, c_in_ld=c4, y2d=y.view(B * H * W, cout),
-                         stride=stride, pad=padding, tag=tag + ".fwd", c_in_real=C)
-        ctx.save_for_backward(x2d, weight)
+                         stride=stride, pad=padding, tag=tag + ".fwd", c_in_real=C, splitk_ws=_splitk_workspace(x.device))
+        ctx.save_for_backward(x2d)
+        ctx.weight = weight                   # the caller's parameter object: the packer tracks it by identity/version
         ctx.geom = (B, C, h, w, c4, cout, k, stride, padding, dilation, up, H, W, tag)
         return y.permute(0, 3, 1, 2)          # [B,cout,H,W] channels_last view
 
     @staticmethod
     def backward(ctx, grad_out):
-        x2d, weight = ctx.saved_tensors
+        x2d, = ctx.saved_tensors
+        weight = ctx.weight
         B, C, h, w, c4, cout, k, stride, padding, dilation, up, H, W, tag = ctx.geom
         dy2d, co4 = _nhwc_rows(grad_out)
         dx = dw = None
@@ -83,12 +189,11 @@ class _ConvFn(torch.autograd.Function):
                 raise BtsHipError("train.conv2d: input gradient is built for stride-1 convolutions with "
                                   "padding <= dilation*(k-1) (every convolution of the BTS decoder and DenseNet "
                                   "body); got stride %d padding %d" % (stride, padding))
-            w_t = weight.detach().flip(2, 3).transpose(0, 1)            # [cin, cout, k, k]
-            wp, _, _ = ops.pack_conv_weight(w_t, c_in_ld=co4)
+            wp = _PACKER.get(weight, co4, WeightPacker.DGRAD)            # flipped, transposed kernel [cin][taps*co4]
             Hs, Ws = h * up, w * up
             dxu = torch.empty((B, Hs, Ws, C), dtype=torch.float32, device=grad_out.device)
             ops.conv_forward(dy2d, B, H, W, wp, C, k, dil=dilation, c_in_ld=co4, y2d=dxu.view(B * Hs * Ws, C),
-                             pad=pad_t, tag=tag + ".dgrad", c_in_real=cout)
+                             pad=pad_t, tag=tag + ".dgrad", c_in_real=cout, splitk_ws=_splitk_workspace(grad_out.device))
             if up == 2:                                                 # adjoint of the nearest-2x upsample
                 dxu = dxu.view(B, h, 2, w, 2, C).sum(dim=(2, 4))
             dx = dxu.permute(0, 3, 1, 2)
@@ -203,6 +308,7 @@ def _conv_elu(seq, x, tag):
 
 def decoder_forward(dec, features, focal):
     """bts.forward in train() mode (bts.py:223-293): same dataflow as the inference path, as an autograd graph."""
+    begin_step()
     skip0, skip1, skip2, skip3 = features[1], features[2], features[3], features[4]
     md = dec.params.max_depth
     cl = torch.channels_last
@@ -284,6 +390,7 @@ def densenet_encoder_forward(enc, x):
     """encoder.forward (bts.py:327-338) for the DenseNet encoders in train() mode: same tap list, convolutions, norm
     layers and their gradients on libbts_hip.so."""
     ops._need(x, "train.encoder")
+    begin_step()
     taps = [x]
     cur = x.float().contiguous(memory_format=torch.channels_last)
     _run_children(list(enc.base_model.named_children()), cur,

@@ -174,6 +174,19 @@ typedef struct bts_conv_wgrad_desc {
 
 int bts_conv_wgrad_f32(const bts_conv_wgrad_desc* desc, bts_stream_t stream);
 
+/* Batched weight re-packing for the training step (the optimiser rewrites the OIHW parameters every iteration,
+ * bts_main.py:606): one launch lays every registered weight out as bts_conv_fwd_f32 wants it.
+ * table: n_entries device records of 12 int64 each --
+ *   { src (OIHW float*), dst (float* [rows_pad][k_pad]), rows, inner, ksize, c_in_ld, rows_pad, k_pad,
+ *     s_row, s_c (element strides of packed row / inner channel in src), flip (1 = spatially flipped taps),
+ *     first_block (prefix sum of bts_pack_weights_blocks over the table) }
+ *   forward layout : rows = c_out, inner = c_in, s_row = c_in*k*k, s_c = k*k, flip 0
+ *   input gradient : rows = c_in, inner = c_out, s_row = k*k, s_c = c_in*k*k, flip 1   (transposed, flipped kernel)
+ * dst[row][tap*c_in_ld + c] = src[row*s_row + c*s_c + (flip ? k*k-1-tap : tap)], zero elsewhere.
+ */
+long bts_pack_weights_blocks(long rows_pad, long k_pad);
+int bts_pack_weights_f32(const void* table, int n_entries, long total_blocks, bts_stream_t stream);
+
 /* Batch-statistic BatchNorm over NHWC rows [npix][C] (nn.BatchNorm2d in train() mode: pytorch/bts.py:69-76,
  * 182-202 and the DenseNet norm layers), C % 4 == 0, row strides % 4 == 0 and >= C (channel slices work in place).
  *

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from bts_amd import bts as M, ops, synth  # noqa: E402
+from bts_amd import bts as M, ops, synth, trainer  # noqa: E402
 
 Params = namedtuple("Params", "encoder bts_size max_depth dataset")
 
@@ -31,14 +31,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--trace", action="store_true")
     ap.add_argument("--decoder-only", action="store_true")
+    ap.add_argument("--no-freeze", action="store_true", help="train every encoder parameter (the reference freezes some)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     params = Params(a.encoder, 512, 80.0, "kitti")
     model = M.BtsModel(params).train().to(dev)
     loss_fn = M.silog_loss(0.85)
-    opt = torch.optim.AdamW([dict(params=model.encoder.parameters(), weight_decay=1e-2),
-                             dict(params=model.decoder.parameters(), weight_decay=0.0)], lr=1e-4, eps=1e-3)
+    if not a.no_freeze:
+        trainer.set_misc(model, a.encoder)          # the reference freezes the stem conv and the encoder norm affines
+    opt = trainer.make_optimizer(model, 1e-4, 1e-2, 1e-3)
     B, H, W = a.batch, a.height, a.width
     x = torch.from_numpy(synth.image_batch(B, H, W, 1)).to(dev)
     focal = torch.from_numpy(synth.focal_values(B, "kitti", 1)).to(dev)
