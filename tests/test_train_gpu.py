@@ -271,3 +271,71 @@ def test_trainer_steps_update_only_trainable_parameters():
             assert not same, n
     assert int(model.decoder.bn5.num_batches_tracked.item()) == 3
     assert model.decoder.lpg8x8.abs_min is not None
+
+
+ADJOINT_CASES = [
+    # the reference training crop (352x704) and the KITTI test size (352x1216): name, B, cin, cout, h, w, k, dil, up
+    ("conv1 @352x1216", 1, 36, 32, 352, 1216, 3, 1, 1),
+    ("upconv1 @176x608 -> 352x1216", 1, 64, 32, 176, 608, 3, 1, 2),
+    ("conv2 @176x352", 4, 164, 64, 176, 352, 3, 1, 1),
+    ("daspp_24 3x3 @44x152", 2, 256, 128, 44, 152, 3, 24, 1),
+    ("daspp_6 1x1 @44x88", 4, 576, 256, 44, 88, 1, 1, 1),
+    ("upconv5 @11x22 -> 22x44", 4, 2208, 512, 11, 22, 3, 1, 2),
+    ("reduc1x1 16->8 @352x704", 4, 16, 8, 352, 704, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", ADJOINT_CASES, ids=lambda c: c[0])
+def test_conv_gradients_are_adjoints_at_full_size(case):
+    """Size-independent property at BASELINE sizes (no CPU reference needed): a convolution is bilinear, so for any
+    x, w, dy:  <conv(x, w), dy>  ==  <x, dgrad(dy)>  ==  <w, wgrad(x, dy)>.  All three inner products come from
+    three different kernels/launch shapes; they must agree to fp32 accumulation accuracy."""
+    from bts_amd import train
+    _, B, cin, cout, h, w, k, dil, up = case
+    gen = torch.Generator(device="cuda").manual_seed(cin * 7 + cout)
+    x = torch.randn(B, cin, h, w, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wt = (torch.randn(cout, cin, k, k, device="cuda", generator=gen) / np.sqrt(cin * k * k)).requires_grad_(True)
+    y = train.conv2d(x, wt, padding=dil * (k // 2), dilation=dil, up=up)
+    dy = torch.randn(y.shape, device="cuda", generator=gen)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    a = (y.detach().double() * dy.double()).sum().item()
+    b = (x.detach().double() * x.grad.double()).sum().item()
+    c = (wt.detach().double() * wt.grad.double()).sum().item()
+    scale = np.sqrt(float(y.numel()))                       # |<y,dy>| ~ sqrt(n) for independent unit-variance entries
+    assert abs(a - b) <= 2e-4 * scale + 1e-5 * abs(a), (a, b, scale)
+    assert abs(a - c) <= 2e-4 * scale + 1e-5 * abs(a), (a, c, scale)
+
+
+def test_decoder_train_step_full_training_crop_vs_oracle():
+    """Decoder training step at the reference's training crop (352x704, arguments_train_eigen.txt) for one frame pair
+    against the CPU oracle in fp32: loss, outputs and the global gradient in relative L2."""
+    from bts_amd import bts as M
+    B, H, W = 2, 352, 704
+    enc, md, ds, _, _ = CONFIGS["K"]
+    feat = synth.ENCODER_CHANNELS[enc]
+    state = O.state_from_numpy(synth.decoder_state(feat, 512, 0))
+    for k, v in state.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    feats, focal = make_inputs("K", B, H, W, 77)
+    gt, mask = synth.train_targets(B, H, W, md, 78)
+    outs_ref = O.decoder_forward(state, feats, focal, md, ds, training=True)
+    loss_ref = O.silog_loss(outs_ref[4], t(gt), t(mask), 0.85)
+    loss_ref.backward()
+    dec = _train_decoder()
+    outs = dec([None] + [f.cuda() for f in feats[1:]], focal.cuda())
+    loss = M.silog_loss(0.85)(outs[4], t(gt).cuda(), t(mask).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    fd, fr = outs[4].detach().cpu(), outs_ref[4].detach()
+    assert ((fd - fr).abs() / fr.abs().clamp_min(1e-3)).max().item() <= 1e-3
+    got = {n: p.grad.cpu().numpy() for n, p in dec.named_parameters()}
+    ref = {n: v.grad.numpy() for n, v in state.items() if v.requires_grad}
+    per, l2 = grad_error_report(got, ref)
+    print("352x704 decoder step vs CPU fp32 oracle: global rel-L2 %.2e, worst tensor %.2e, 90th pct %.2e"
+          % (l2, max(per.values()), sorted(per.values())[int(0.9 * (len(per) - 1))]))
+    # fp32 against fp32 (both sides carry their own rounding / ReLU-mask flips; per-tensor maxima over up to 10 M
+    # elements): per-tensor bars are loose, the global relative L2 -- measured 3.3e-4 -- is the tight one
+    assert_grads_close(per, l2, "352x704 decoder step", typical=1e-2, worst=0.2, l2=2e-3)
