@@ -33,7 +33,22 @@ def main():
     ap.add_argument("--decoder-only", action="store_true")
     ap.add_argument("--no-freeze", action="store_true", help="train every encoder parameter (the reference freezes some)")
     a = ap.parse_args()
-    dev = torch.device("cuda:0")
+    # BASELINE config 5 (B=32 over 8 GPUs = 4 per GPU, DDP): launch with
+    #   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/train_bench.py
+    import os
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1 or os.environ.get("BTS_BENCH_FORCE_DIST") == "1"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    saved_stdout = os.dup(1)                 # RCCL prints a banner on stdout: keep the JSON line clean
+    os.dup2(2, 1)
     torch.manual_seed(0)
     params = Params(a.encoder, 512, 80.0, "kitti")
     model = M.BtsModel(params).train().to(dev)
@@ -41,6 +56,9 @@ def main():
     if not a.no_freeze:
         trainer.set_misc(model, a.encoder)          # the reference freezes the stem conv and the encoder norm affines
     opt = trainer.make_optimizer(model, 1e-4, 1e-2, 1e-3)
+    core = model
+    if use_dist:
+        model = trainer.wrap_ddp(model, dev)   # gradient all-reduce over RCCL, overlapped with backward by DDP's buckets
     B, H, W = a.batch, a.height, a.width
     x = torch.from_numpy(synth.image_batch(B, H, W, 1)).to(dev)
     focal = torch.from_numpy(synth.focal_values(B, "kitti", 1)).to(dev)
@@ -53,7 +71,7 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        outs = model.decoder(feats, focal) if a.decoder_only else model(x, focal)
+        outs = core.decoder(feats, focal) if a.decoder_only else model(x, focal)
         loss = loss_fn(outs[4], gt, mask)
         loss.backward()
         opt.step()
@@ -65,13 +83,21 @@ def main():
         torch.cuda.synchronize()
         print("warmup %d: %.1f ms loss %.4f" % (i, (time.time() - t0) * 1e3, l.item()), file=sys.stderr, flush=True)
     torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
     t0 = time.time()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
     ms = (time.time() - t0) * 1e3 / a.steps
-    res = dict(metric="training step ms (fwd+loss+bwd+AdamW)", ms_per_step=ms, frames_per_s=B / ms * 1e3,
-               config=dict(encoder=a.encoder, batch=B, height=H, width=W, decoder_only=a.decoder_only),
+    if use_dist:
+        dist.barrier()
+        tmax = torch.tensor([ms], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ms = tmax.item()
+    res = dict(metric="training step ms (fwd+loss+bwd+AdamW)", ms_per_step=ms, frames_per_s=world * B / ms * 1e3,
+               n_gpus=world, ddp=use_dist,
+               config=dict(encoder=a.encoder, batch_per_gpu=B, height=H, width=W, decoder_only=a.decoder_only),
                peak_mem_gb=torch.cuda.max_memory_allocated() / 2**30)
     if a.trace:
         tr = ops.KernelTrace()
@@ -97,7 +123,10 @@ def main():
         top.sort(reverse=True)
         for ms_, kern, tag, n, tf in top[:25]:
             print("%8.2f ms  %-34s %-22s x%-4d %6.1f TF/s" % (ms_, kern, tag, n, tf), file=sys.stderr)
-    print(json.dumps(res))
+    if rank == 0:
+        os.write(saved_stdout, (json.dumps(res) + "\n").encode())
+    if use_dist:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
