@@ -397,7 +397,9 @@ class bts(nn.Module):
         already filled; ``dense2d``: the 1/32-resolution features [npix, C>=f[4]] and the prologue
         (affine, relu) still to be applied to them (norm5 + ReLU when the encoder is fused in).
         ``outs``: optional 6 preallocated contiguous result tensors (e.g. batch slices of full-batch tensors)."""
-        _require_eval(self, "bts")
+        if self.training:
+            raise BtsHipError("bts.forward_nhwc is the fused inference path; train() mode goes through bts.forward "
+                              "(bts_amd/train.py)")
         dev = dense2d.device
         nf, f = self.num_features, self.feat_out_channels
         md = float(self.params.max_depth)

@@ -79,17 +79,19 @@ def test_decoder_full_size_b16_properties(decoders, cname):
     assert (full[3] > 0).all() and (full[3] < 1).all()
 
 
-def test_decoder_rejects_cpu_and_train(decoders):
+def test_decoder_rejects_cpu_tensors_in_both_modes(decoders):
+    """No CPU fallback: host tensors raise in eval and in train() mode; train() mode on the GPU builds the autograd
+    graph of bts_amd/train.py (checked in depth by tests/test_train_gpu.py)."""
+    import copy
     dec = decoders["K"]
     feats, focal = make_inputs("K", 1, 64, 96, 1)
     with pytest.raises(RuntimeError):
         dec(feats, focal)                         # CPU tensors: no fallback
-    dec.train()
-    try:
-        with pytest.raises(NotImplementedError):
-            dec([None] + [f.cuda() for f in feats[1:]], focal.cuda())
-    finally:
-        dec.eval()
+    tr = copy.deepcopy(dec).train()               # a copy: train() mode updates the BN running buffers
+    with pytest.raises(RuntimeError):
+        tr(feats, focal)
+    outs = tr([None] + [f.cuda() for f in feats[1:]], focal.cuda())
+    assert len(outs) == 6 and outs[4].requires_grad and tuple(outs[4].shape) == (1, 1, 64, 96)
 
 
 def test_decoder_validates_tap_shapes(decoders):
