@@ -14,6 +14,8 @@ kernels' layouts after ``load_state_dict``.
 Inside ``bts.forward`` everything is NHWC: every convolution of the decoder is one launch of the
 fp32-MFMA implicit-GEMM kernel with its BN/ReLU/ELU fused, concatenations are channel slices of
 preallocated buffers (no torch.cat), each reduction_1x1 stack is one kernel, each LPG one kernel.
+In ``train()`` mode (bts_main.py) the same modules build an autograd graph instead -- batch-statistic BN and every
+convolution's forward / input gradient / weight gradient on the HIP kernels, see ``bts_amd/train.py``.
 There is no PyTorch/CPU fallback: CPU tensors or a missing libbts_hip.so raise.
 """
 from __future__ import annotations

@@ -19,7 +19,7 @@ There is no CPU path here: non-CUDA tensors raise.
 from __future__ import annotations
 
 import weakref
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 import torch.nn.functional as F

@@ -8,7 +8,7 @@ photometric losses (external ``c3d`` package), TensorBoard and checkpoint rotati
 """
 from __future__ import annotations
 
-from typing import Iterable, Optional
+from typing import Optional
 
 import torch
 import torch.distributed as dist
