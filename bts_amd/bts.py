@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from . import ops, train
 from ._lib import BtsHipError
+from . import encoders
 from .encoders import build_base_model
 
 
@@ -542,18 +543,20 @@ class BtsModel(nn.Module):
         self._side_streams = {}
 
     def _native_ok(self, x):
-        return (self.native_encoder and 'densenet' in self.encoder.params.encoder and not self.training
-                and isinstance(x, torch.Tensor) and x.is_cuda)
+        return (self.native_encoder and not self.training and isinstance(x, torch.Tensor) and x.is_cuda
+                and isinstance(self.encoder.base_model, (nn.Sequential, encoders.ResNet)))
 
     def _forward_native(self, x, focal, slot, outs=None):
-        from .encoder_hip import DenseNetHip
-        if self._enc_hip is None or self._enc_hip.features is not self.encoder.base_model:
-            self._enc_hip = DenseNetHip(self.encoder.base_model)
+        from .encoder_hip import DenseNetHip, ResNetHip
+        base = self.encoder.base_model
+        if self._enc_hip is None or getattr(self._enc_hip, "features", getattr(self._enc_hip, "model", None)) is not base:
+            self._enc_hip = ResNetHip(base) if isinstance(base, encoders.ResNet) else DenseNetHip(base)
         B, _, H, W = x.shape
         dec = self.decoder
         ws = dec._workspace(B, H, W, x.device, slot)
         r = self._enc_hip.run(x.float(), dec.skip_slots(ws), slot=slot)
-        return dec.forward_nhwc(ws, B, H, W, focal, r["dense"], r["norm5"], True, outs=outs)
+        # DenseNet: norm5 + ReLU become the prologue of the decoder's first conv; ResNet: layer4 is already ReLU'd
+        return dec.forward_nhwc(ws, B, H, W, focal, r["dense"], r["norm5"], r["norm5"] is not None, outs=outs)
 
     def forward(self, x, focal):
         if self.training and self.native_encoder and 'densenet' in self.encoder.params.encoder \

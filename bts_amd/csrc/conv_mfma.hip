@@ -56,6 +56,11 @@ struct ConvArgs {
     // fp32 partial sums to ws[s][m][n] (row length ws_ld); splitk_reduce_kernel sums them and applies the epilogue
     int ksplit, its_per_split, ws_ld;
     float* ws;
+    // grouped convolution as `n_classes` independent channel bundles (bts_conv_desc.n_bundles): bundle j reads input
+    // channels [j*c_in_ld, ..), writes output channels [j*c_out, ..), uses weight block j and the j-th c_out_pad / c_in_ld
+    // slice of the epilogue / prologue vectors.  bundled == 0: plain (n_classes 1) or sub-pixel (n_classes 4).
+    int n_classes, bundled;
+    const float* res; long res_pix_stride;   // optional residual added after e1, before the activation (NHWC)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -167,7 +172,7 @@ __device__ __forceinline__ void stage_to_lds(const ConvArgs& a, float* __restric
 // MF = 32: v_mfma_f32_32x32x2_f32 tiles (default).  MF = 16: v_mfma_f32_16x16x4_f32 tiles, same FLOP rate
 // but 16-column granularity -- used for c_out = 48 (DenseNet growth) where a 64-wide tile wastes 25 %.
 template <int BM, int BN, int WM, int WN, int MF, bool NCHW_OUT>
-__global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a0) {
     constexpr int NT = WM * WN * 64;          // threads per workgroup (4 or 8 waves)
     constexpr int RPP = NT / 8;               // tile rows staged per pass (8 lanes x 16 B per row)
     constexpr int TM = BM / WM / MF, TN = BN / WN / MF;
@@ -185,11 +190,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     // XCD-aware block remap (bijective): blocks sharing an XCD (bid % 8) get a contiguous range of
     // tiles, so neighbouring pixel tiles (shared halo rows) and the N tiles of one M tile share an L2.
     const int nwg = gridDim.x, bid = blockIdx.x;
+    const int tiles_all0 = a0.tiles_per_class * a0.n_classes;
+    ConvArgs a = a0;
+    if (a0.bundled) {                         // wave-uniform: re-base every per-channel pointer onto this block's bundle
+        const int xcd0 = bid & 7, qq0 = nwg >> 3, rr0 = nwg & 7;
+        const int swz0 = (xcd0 < rr0 ? xcd0 * (qq0 + 1) : rr0 * (qq0 + 1) + (xcd0 - rr0) * qq0) + (bid >> 3);
+        const int j = (swz0 % tiles_all0) / a0.tiles_per_class;
+        a.x += (size_t)j * a0.c_in_ld;
+        a.y += (size_t)j * a0.c_out;
+        if (a0.y2) a.y2 += (size_t)j * a0.c_out;
+        if (a0.res) a.res += (size_t)j * a0.c_out;
+        if (a0.pre_scale) { a.pre_scale += (size_t)j * a0.c_in_ld; a.pre_shift += (size_t)j * a0.c_in_ld; }
+        if (a0.e1_scale) { a.e1_scale += (size_t)j * a0.c_out_pad; a.e1_shift += (size_t)j * a0.c_out_pad; }
+        if (a0.e2_scale) { a.e2_scale += (size_t)j * a0.c_out_pad; a.e2_shift += (size_t)j * a0.c_out_pad; }
+    }
     const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
     // sub-pixel upconv: the grid covers 4 parity classes (py,px) of output pixels, each its own GEMM over the
     // SOURCE pixels with a 2x2 kernel (weights pre-summed per class) -- see bts_conv_desc.subpixel
-    const int tiles_all = a.tiles_per_class * (a.subpix ? 4 : 1);
+    const int tiles_all = a.tiles_per_class * a.n_classes;
     const int split = swz / tiles_all;
     const int srem = swz - split * tiles_all;
     const int cls = srem / a.tiles_per_class;
@@ -363,6 +382,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
                     const long m = m0 + (wm * TM + i) * MF + drow;
                     float v = acc[i][j][r];
                     if (has_e1) v = v * s1 + b1;
+                    if (a.res != nullptr && nok && m < a.M) v += a.res[m * a.res_pix_stride + n];
                     v = apply_act(v, a.act);
                     if (has_e2) v = v * s2 + b2;
                     if (nok && m < a.M) {
@@ -408,6 +428,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, in
         float v = 0.f;
         for (int sidx = 0; sidx < a.ksplit; ++sidx) v += a.ws[((size_t)sidx * a.M + m) * a.ws_ld + n];
         if (a.e1_scale) v = v * a.e1_scale[n] + a.e1_shift[n];
+        if (a.res) v += a.res[m * a.res_pix_stride + n];
         v = apply_act(v, a.act);
         if (a.e2_scale) v = v * a.e2_scale[n] + a.e2_shift[n];
         if (nchw) {
@@ -426,7 +447,7 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     const long n_mtiles = (a.M + BM - 1) / BM;
     a.n_ntiles = (a.c_out + BN - 1) / BN;            // tiles over REAL channels; wrow clamps into c_out_pad
     a.tiles_per_class = (int)(n_mtiles * a.n_ntiles);
-    const long tiles = n_mtiles * a.n_ntiles * (a.subpix ? 4 : 1);
+    const long tiles = n_mtiles * a.n_ntiles * a.n_classes;
     // split-K when the grid would leave most of the 256 CUs idle (M-starved deep encoder layers) and the caller
     // lent a workspace.  The split factor is a function of the PER-FRAME geometry only (H*W, c_out, K) -- sized for
     // the nominal 8-frame sub-batch -- never of the batch size: an output element's summation order, hence its
@@ -435,7 +456,7 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     a.ksplit = 1; a.its_per_split = nit_all; a.ws_ld = (a.c_out + 3) & ~3;
     static const int split_max = getenv("BTS_CONV_SPLITK") ? atoi(getenv("BTS_CONV_SPLITK")) : 8;
     static const long split_below = getenv("BTS_CONV_SPLITK_BELOW") ? atol(getenv("BTS_CONV_SPLITK_BELOW")) : 700;
-    if (!a.subpix && a.ws != nullptr && split_max > 1) {
+    if (a.n_classes == 1 && a.ws != nullptr && split_max > 1) {
         const long tiles64 = ((8L * a.H * a.W + 63) / 64) * a.n_ntiles;     // 64-row tiles of a nominal 8-frame launch
         if (tiles64 < split_below) {
             static const long split_target = getenv("BTS_CONV_SPLITK_TARGET") ? atol(getenv("BTS_CONV_SPLITK_TARGET")) : 1024;
@@ -555,6 +576,19 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if (a.H <= 0 || a.W <= 0) return BTS_ERR_INVALID;
     a.M = (long)d->B * a.H * a.W;
     a.n_ntiles = 0; a.tiles_per_class = 0;
+    a.n_classes = a.subpix ? 4 : 1; a.bundled = 0;
+    a.res = d->res; a.res_pix_stride = d->res_pix_stride;
+    if (d->res && (d->y_nchw || d->res_pix_stride < d->c_out)) return BTS_ERR_INVALID;
+    if (d->n_bundles > 1) {
+        if (d->subpixel || d->y_nchw || d->up != 1) return BTS_ERR_INVALID;
+        if (d->c_out_pad != d->c_out) return BTS_ERR_INVALID;                 // bundle outputs tile the channel axis exactly
+        if (d->x_pix_stride < (long)d->n_bundles * d->c_in_ld || d->y_pix_stride < (long)d->n_bundles * d->c_out)
+            return BTS_ERR_INVALID;
+        if (d->y2 && d->y2_pix_stride < (long)d->n_bundles * d->c_out) return BTS_ERR_INVALID;
+        if (d->res && d->res_pix_stride < (long)d->n_bundles * d->c_out) return BTS_ERR_INVALID;
+        if ((double)d->n_bundles * d->c_out_pad * (double)d->k_pad >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
+        a.n_classes = d->n_bundles; a.bundled = 1;
+    } else if (d->n_bundles < 0) return BTS_ERR_INVALID;
     a.ksplit = 1; a.its_per_split = 0; a.ws_ld = 0;
     a.ws = d->splitk_ws;
     const long wsf = d->splitk_ws ? d->splitk_ws_floats : 0;
@@ -562,7 +596,7 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool nchw = d->y_nchw != 0;
     int bm, bn;
-    choose_tile(a.M * (a.subpix ? 4 : 1), d->c_out, &bm, &bn);
+    choose_tile(a.M * a.n_classes, d->c_out, &bm, &bn);
     if (bn == 48) return bm == 128 ? launch_conv<128, 48, 4, 1, 16>(a, nchw, s, wsf) : launch_conv<64, 48, 4, 1, 16>(a, nchw, s, wsf);
     // 8-wave workgroups (two waves per SIMD from the same tile) for the 128-row tiles: +2 % end to end over the
     // 4-wave layout on MI355X (more waves to cover each other's staging); BTS_CONV_W8=0 selects the 4-wave kernels
@@ -585,6 +619,6 @@ extern "C" int bts_conv_plan_f32(const bts_conv_desc* d, int* bm, int* bn) {
     long H = (Hs + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
     long W = (Ws + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
     if (d->subpixel) { H = 2L * d->h_in; W = 2L * d->w_in; }
-    choose_tile((long)d->B * H * W, d->c_out, bm, bn);
+    choose_tile((long)d->B * H * W * (d->n_bundles > 1 ? d->n_bundles : 1), d->c_out, bm, bn);
     return 0;
 }

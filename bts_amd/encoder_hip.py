@@ -167,3 +167,143 @@ class DenseNetHip:
         n5 = d * sc[: d.shape[1]] + sh[: d.shape[1]]          # norm5 is fused into the decoder; materialise it here only
         outs.append(ops.nhwc_to_nchw(n5.contiguous(), B, H // 32, W // 32))
         return outs
+
+
+class ResNetHip:
+    """Execution plan for ``encoders.ResNet`` (torchvision ResNet-50/101, ResNeXt-50 32x4d / -101 32x8d) in eval mode.
+
+    Every convolution of a bottleneck is one launch of the conv kernel with its BatchNorm folded into the epilogue:
+    conv1 1x1 (+BN+ReLU), conv2 3x3 (stride, groups; +BN+ReLU), the optional 1x1 strided downsample (+BN), and conv3
+    1x1 whose epilogue adds the identity and applies the final ReLU (``bts_conv_desc.res``).  ResNeXt's 32-group 3x3
+    runs as ONE launch over channel bundles (``bts_conv_desc.n_bundles``): consecutive groups packed block-diagonally
+    into >= 32-channel bundles, so the MFMA tiles stay full at the price of (32 / channels-per-group)x redundant
+    FLOPs on the two shallow stages only.  The taps the decoder needs (relu, layer1..3; reference bts.py:318-338) are
+    written straight into its concat buffers; layer4's output is the decoder's dense input."""
+
+    def __init__(self, model: nn.Module):
+        self.model = model
+        self._pack = None
+        self._pack_key = None
+        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        self.layers = [model.layer1, model.layer2, model.layer3, model.layer4]
+        self.c_stem = model.conv1.out_channels
+        self.c_out = [l[-1].conv3.out_channels for l in self.layers]
+        self.width = [l[0].conv2.out_channels for l in self.layers]
+
+    def packed(self):
+        key = _key(self.model)
+        if self._pack is not None and self._pack_key == key:
+            return self._pack
+        m = self.model
+        w0, co0, _ = ops.pack_conv_weight(m.conv1.weight.detach(), c_in_ld=4)
+        P = dict(stem=dict(w=w0, e1=_bn_vecs(m.bn1, co0)), layers=[])
+        for layer in self.layers:
+            blocks = []
+            for blk in layer:
+                w1, co1, _ = ops.pack_conv_weight(blk.conv1.weight.detach())
+                g = blk.conv2.groups
+                if g > 1:
+                    w2, nb, cb = ops.pack_grouped_conv_weight(blk.conv2.weight.detach(), g)
+                else:
+                    w2, _, _ = ops.pack_conv_weight(blk.conv2.weight.detach())
+                    nb, cb = 1, blk.conv2.out_channels
+                w3, co3, _ = ops.pack_conv_weight(blk.conv3.weight.detach())
+                width = blk.conv2.out_channels
+                b = dict(w1=w1, e1=_bn_vecs(blk.bn1, co1), w2=w2, nb=nb, cb=cb, cg=blk.conv2.in_channels // g,
+                         e2=_bn_vecs(blk.bn2, ops.round_up(width, 32)), w3=w3, e3=_bn_vecs(blk.bn3, co3),
+                         stride=blk.conv2.stride[0], width=width, c_out=blk.conv3.out_channels, down=None)
+                if blk.downsample is not None:
+                    wd, cod, _ = ops.pack_conv_weight(blk.downsample[0].weight.detach())
+                    b["down"] = dict(w=wd, e1=_bn_vecs(blk.downsample[1], cod), stride=blk.downsample[0].stride[0])
+                blocks.append(b)
+            P["layers"].append(blocks)
+        self._pack, self._pack_key = P, key
+        return P
+
+    def _workspace(self, B, H, W, device, slot=0):
+        key = (B, H, W, str(device), slot)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        n = [B * (H // s) * (W // s) for s in (1, 2, 4, 8, 16, 32)]
+
+        def z(npix, c):
+            return torch.zeros((npix, c), dtype=torch.float32, device=device)
+
+        ws = dict(img=z(n[0], 4), x0=z(n[2], self.c_stem))
+        ws["splitk"] = torch.empty(8 * n[3] * 512, dtype=torch.float32, device=device)
+        for li in range(4):
+            px_in, px = n[2 + max(li - 1, 0)] if li else n[2], n[2 + li]
+            ws["t1_%d" % li] = z(max(px_in, px), self.width[li])
+            ws["t2_%d" % li] = z(px, self.width[li])
+            ws["idn_%d" % li] = z(px, self.c_out[li])
+            ws["a_%d" % li] = z(px, self.c_out[li])
+            ws["b_%d" % li] = z(px, self.c_out[li])
+        if len(self._ws) >= 8:
+            self._ws.clear()
+        self._ws[key] = ws
+        return ws
+
+    def run(self, x: torch.Tensor, skip_dst: Optional[List[Optional[torch.Tensor]]] = None, slot: int = 0):
+        """x [B,3,H,W] NCHW -> dict(dense=[npix/32^2, c_out[3]] NHWC (layer4, already ReLU'd), norm5=None, skips=...).
+        ``skip_dst``: four optional NHWC views receiving relu (H/2), layer1 (H/4), layer2 (H/8), layer3 (H/16)."""
+        ops._need(x, "ResNetHip.run")
+        B, C, H, W = x.shape
+        if C != 3 or H % 32 or W % 32:
+            raise ops.BtsHipError("ResNetHip: expected [B,3,H,W] with H,W multiples of 32")
+        dev = x.device
+        P = self.packed()
+        ws = self._workspace(B, H, W, dev, slot)
+        skip_dst = list(skip_dst) if skip_dst is not None else [None] * 4
+        hs = [H // s for s in (2, 4, 8, 16, 32)]
+        wss = [W // s for s in (2, 4, 8, 16, 32)]
+        taps_c = [self.c_stem] + self.c_out[:3]
+        for i in range(4):
+            if skip_dst[i] is None:
+                skip_dst[i] = torch.empty((B * hs[i] * wss[i], taps_c[i]), dtype=torch.float32, device=dev)
+        RELU = ops.ACT_RELU
+        sk = ws["splitk"]
+
+        ops.nchw_to_nhwc(x, ws["img"][:, :3])
+        ops.conv_forward(ws["img"], B, H, W, P["stem"]["w"], self.c_stem, 7, stride=2, pad=3, e1=P["stem"]["e1"], act=RELU,
+                         y2d=skip_dst[0], tag="enc_stem", c_in_real=3)
+        ops.maxpool3x3s2(skip_dst[0], B, hs[0], wss[0], ws["x0"])
+        cur, h, w = ws["x0"], hs[1], wss[1]
+        for li, blocks in enumerate(P["layers"]):
+            tag = "enc_l%d" % (li + 1)
+            for bi, b in enumerate(blocks):
+                s = b["stride"]
+                ho, wo = h // s, w // s
+                t1 = ws["t1_%d" % li][: B * h * w]
+                t2 = ws["t2_%d" % li][: B * ho * wo]
+                ops.conv_forward(cur, B, h, w, b["w1"], b["width"], 1, e1=b["e1"], act=RELU, y2d=t1, tag=tag + "_1x1",
+                                 splitk_ws=sk)
+                if b["nb"] > 1:
+                    ops.conv_forward(t1, B, h, w, b["w2"], b["cb"], 3, stride=s, pad=1, c_in_ld=b["cb"], e1=b["e2"], act=RELU,
+                                     y2d=t2, n_bundles=b["nb"], tag=tag + "_g3x3", c_in_real=b["cg"])
+                else:
+                    ops.conv_forward(t1, B, h, w, b["w2"], b["width"], 3, stride=s, pad=1, e1=b["e2"], act=RELU, y2d=t2,
+                                     tag=tag + "_3x3", splitk_ws=sk)
+                if b["down"] is not None:
+                    idn = ws["idn_%d" % li][: B * ho * wo]
+                    ops.conv_forward(cur, B, h, w, b["down"]["w"], b["c_out"], 1, stride=b["down"]["stride"], pad=0,
+                                     e1=b["down"]["e1"], y2d=idn, tag=tag + "_down", splitk_ws=sk)
+                else:
+                    idn = cur
+                out = ws["a_%d" % li] if (bi % 2 == 0) else ws["b_%d" % li]
+                last = bi == len(blocks) - 1
+                ops.conv_forward(t2, B, ho, wo, b["w3"], b["c_out"], 1, e1=b["e3"], act=RELU, y2d=out, res2d=idn,
+                                 y2_2d=skip_dst[li + 1] if (last and li < 3) else None, tag=tag + "_1x1", splitk_ws=sk)
+                cur, h, w = out, ho, wo
+        return dict(dense=cur, norm5=None, skips=skip_dst, B=B, H=H, W=W)
+
+    def taps_nchw(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """The reference ``encoder.forward`` list [x, relu, layer1, layer2, layer3, layer4] as NCHW tensors
+        (bts.py:327-338), computed on the HIP path."""
+        r = self.run(x)
+        B, H, W = r["B"], r["H"], r["W"]
+        outs = [x]
+        for i, s in enumerate(r["skips"]):
+            outs.append(ops.nhwc_to_nchw(s, B, H // (2 << i), W // (2 << i)))
+        outs.append(ops.nhwc_to_nchw(r["dense"], B, H // 32, W // 32))
+        return outs

@@ -284,6 +284,26 @@ def pack_conv_weight(w: torch.Tensor, perm: Optional[torch.Tensor] = None,
     return out.contiguous(), cout_pad, c_in_ld
 
 
+def pack_grouped_conv_weight(w: torch.Tensor, groups: int) -> Tuple[torch.Tensor, int, int]:
+    """Grouped [c, c/groups, k, k] weight (cin == cout == c, ResNeXt's 3x3) -> [n_bundles, cb, k_pad] for
+    conv_forward(n_bundles=...): consecutive groups are packed block-diagonally into bundles of cb = max(32, c/groups)
+    channels, so each bundle is an ordinary dense convolution over its own cb input channels.
+    Returns (packed, n_bundles, cb)."""
+    c, cg, kh, kw = w.shape
+    if c != cg * groups:
+        raise BtsHipError("pack_grouped_conv_weight: expected cin == cout == groups * channels-per-group")
+    cb = max(32, cg)
+    if cb % cg or c % cb or cb % 32:
+        raise BtsHipError("pack_grouped_conv_weight: unsupported group width %d" % cg)
+    nb, gpb = c // cb, cb // cg                             # bundles, groups per bundle
+    dense = torch.zeros((nb, cb, cb, kh, kw), dtype=torch.float32, device=w.device)
+    wv = w.float().reshape(nb, gpb, cg, cg, kh, kw)         # [bundle, group-in-bundle, out-in-group, in-in-group, k, k]
+    for g in range(gpb):
+        dense[:, g * cg:(g + 1) * cg, g * cg:(g + 1) * cg] = wv[:, g]
+    packed = torch.stack([pack_conv_weight(dense[j], c_in_ld=cb)[0] for j in range(nb)])
+    return packed.contiguous(), nb, cb
+
+
 _SUBPIX_SETS = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}   # (parity, tap) -> 3x3 kernel rows summed
 
 
@@ -340,12 +360,15 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
                  y2d: Optional[torch.Tensor] = None, y_nchw: Optional[torch.Tensor] = None,
                  tag: str = "conv", c_in_real: Optional[int] = None, stride: int = 1, pad: Optional[int] = None,
                  y2_2d: Optional[torch.Tensor] = None, subpixel: bool = False,
-                 splitk_ws: Optional[torch.Tensor] = None):
+                 splitk_ws: Optional[torch.Tensor] = None, res2d: Optional[torch.Tensor] = None, n_bundles: int = 1):
     """One fused convolution (see bts_conv_desc in include/bts_hip.h).
     ``subpixel``: w_packed comes from pack_upconv_subpixel; computes nearest-2x + conv3x3 (pass ksize=3, up=2).
 
     x2d: [B*h_in*w_in, C>=c_in_ld] NHWC view.  Exactly one of y2d ([B*H*W, c_out] NHWC view) /
-    y_nchw ([B,c_out,H,W] contiguous) receives the result.  pad defaults to dil*(ksize//2)."""
+    y_nchw ([B,c_out,H,W] contiguous) receives the result.  pad defaults to dil*(ksize//2).
+    ``res2d``: residual [B*H*W, c_out] added after e1, before the activation.  ``n_bundles`` > 1: grouped convolution
+    as independent channel bundles (w_packed [n_bundles, c_out_pad, k_pad] from pack_grouped_conv_weight; c_in_ld /
+    c_out are PER BUNDLE, x2d / y2d hold all n_bundles*c_in_ld / n_bundles*c_out channels)."""
     xs, xc = _rows2d(x2d, "conv_forward")
     _need(w_packed, "conv_forward")
     if c_in_ld is None:
@@ -356,13 +379,18 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
             raise BtsHipError("conv_forward: subpixel needs ksize=3, up=2 and weights from pack_upconv_subpixel")
         _, c_out_pad, k_pad = w_packed.shape
         taps = 4
+    elif n_bundles > 1:
+        if w_packed.dim() != 3 or w_packed.shape[0] != n_bundles or c_in_ld is None:
+            raise BtsHipError("conv_forward: bundled weights must be [n_bundles, c_out_pad, k_pad] with c_in_ld per bundle")
+        _, c_out_pad, k_pad = w_packed.shape
+        taps = ksize * ksize
     else:
         c_out_pad, k_pad = w_packed.shape
         taps = ksize * ksize
     if k_pad != round_up(taps * c_in_ld, 32) or not w_packed.is_contiguous():
         raise BtsHipError("conv_forward: packed weight [%d,%d] does not match ksize %d / c_in_ld %d"
                           % (c_out_pad, k_pad, ksize, c_in_ld))
-    if c_in_ld % 4 or c_in_ld > xc or x2d.shape[0] != B * h_in * w_in:
+    if c_in_ld % 4 or c_in_ld * n_bundles > xc or x2d.shape[0] != B * h_in * w_in:
         raise BtsHipError("conv_forward: bad input view (c_in_ld %d, view %s)" % (c_in_ld, tuple(x2d.shape)))
     if pad is None:
         pad = dil * (ksize // 2)
@@ -375,7 +403,8 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         d.up, d.ksize, d.pad, d.subpixel = 1, 2, 0, 1
     d.w, d.c_out, d.c_out_pad = w_packed.data_ptr(), c_out, c_out_pad
     keep = []
-    for name, pair, n in (("pre", pre, c_in_ld), ("e1", e1, c_out_pad), ("e2", e2, c_out_pad)):
+    d.n_bundles = n_bundles if n_bundles > 1 else 0
+    for name, pair, n in (("pre", pre, c_in_ld * n_bundles), ("e1", e1, c_out_pad * n_bundles), ("e2", e2, c_out_pad * n_bundles)):
         if pair is not None:
             s, b = pair
             if s.numel() != n or b.numel() != n:
@@ -390,16 +419,23 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         raise BtsHipError("conv_forward: give exactly one of y2d / y_nchw")
     if y2d is not None:
         ys, yc = _rows2d(y2d, "conv_forward")
-        if yc != c_out or y2d.shape[0] != B * H * W:
+        if yc != c_out * n_bundles or y2d.shape[0] != B * H * W:
             raise BtsHipError("conv_forward: bad output view")
         d.y, d.y_pix_stride, d.y_nchw = y2d.data_ptr(), ys, 0
         out = y2d
         if y2_2d is not None:
             y2s, y2c = _rows2d(y2_2d, "conv_forward")
-            if y2c != c_out or y2_2d.shape[0] != B * H * W:
+            if y2c != c_out * n_bundles or y2_2d.shape[0] != B * H * W:
                 raise BtsHipError("conv_forward: bad second output view")
             d.y2, d.y2_pix_stride = y2_2d.data_ptr(), y2s
+        if res2d is not None:
+            rs, rc = _rows2d(res2d, "conv_forward")
+            if rc != c_out * n_bundles or res2d.shape[0] != B * H * W:
+                raise BtsHipError("conv_forward: bad residual view %s" % (tuple(res2d.shape),))
+            d.res, d.res_pix_stride = res2d.data_ptr(), rs
     else:
+        if res2d is not None or n_bundles > 1:
+            raise BtsHipError("conv_forward: residual / bundled convolutions write NHWC only")
         _need(y_nchw, "conv_forward")
         if tuple(y_nchw.shape) != (B, c_out, H, W) or not y_nchw.is_contiguous():
             raise BtsHipError("conv_forward: y_nchw must be contiguous [B,c_out,H,W]")
@@ -412,6 +448,8 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         d.splitk_ws, d.splitk_ws_floats = splitk_ws.data_ptr(), splitk_ws.numel()
     cin = c_in_real if c_in_real is not None else c_in_ld
     npix_out = B * H * W
+    if n_bundles > 1:                                      # algorithmic FLOPs of the grouped conv are passed in c_in_real
+        c_out = c_out * n_bundles                          # (real input channels per OUTPUT channel = channels per group)
     flops = 2.0 * npix_out * c_out * cin * flops_taps      # algorithmic: the reference's 3x3 on the upsampled map
     nbytes = 4.0 * (B * h_in * w_in * cin + npix_out * c_out + flops_taps * c_out * cin)
     variant = "conv"
@@ -421,7 +459,7 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         variant = "conv_fwd_kernel<%d,%d,%s>" % (bm.value, bn.value, "nchw" if y_nchw is not None else "nhwc")
     with torch.cuda.device(x2d.device):
         rc = _launch(variant, tag, flops, nbytes, lambda: _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d)),
-                     xflops=2.0 * npix_out * c_out * cin * taps)
+                     xflops=2.0 * npix_out * c_out * (c_in_ld if n_bundles > 1 else cin) * taps)
     _lib.check(rc, "bts_conv_fwd_f32")
     return out
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 1
+#define BTS_HIP_ABI_VERSION 2
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -138,6 +138,17 @@ typedef struct bts_conv_desc {
                                 lets under-filled launches split K over several workgroups: partial sums go here
                                 and a second kernel reduces them in a fixed order (deterministic); NULL = never split */
     long  splitk_ws_floats;  /* its size in floats (8 * M * round_up(c_out,4) is always enough)                     */
+    const float* res;        /* optional residual, NHWC [B,H,W,>=c_out]: y = act(e1(conv) + res) -- the bottleneck's
+                                `out += identity; relu` of the ResNet/ResNeXt encoders (torchvision Bottleneck.forward,
+                                caller side of pytorch/bts.py:327-338); NULL = none; NHWC output only                 */
+    long  res_pix_stride;
+    int   n_bundles;         /* 0/1: ordinary convolution.  > 1: grouped convolution run as n_bundles independent
+                                channel bundles in ONE launch (ResNeXt's 32-group 3x3, groups packed block-diagonally
+                                into bundles of >= 32 channels by the host): bundle j reads input channels
+                                [j*c_in_ld, (j+1)*c_in_ld) and writes output channels [j*c_out, (j+1)*c_out);
+                                w = [n_bundles][c_out_pad][k_pad]; pre_* hold n_bundles*c_in_ld and e1_/e2_*
+                                n_bundles*c_out_pad entries; x_pix_stride >= n_bundles*c_in_ld,
+                                y_pix_stride >= n_bundles*c_out; no sub-pixel, NCHW output or split-K               */
 } bts_conv_desc;
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);

@@ -196,3 +196,94 @@ def test_pooling_kernels():
     ops.bn_relu_avgpool2(src, B, h, w, sc.cuda(), sh.cuda(), dst)
     ref = F.avg_pool2d(F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 2, 2)
     torch.testing.assert_close(ops.nhwc_to_nchw(dst, B, h // 2, w // 2).cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("c,groups,stride,hw", [(128, 32, 1, (9, 13)), (256, 32, 2, (10, 14)), (512, 32, 1, (5, 7)),
+                                                (1024, 32, 2, (6, 8)), (2048, 32, 1, (3, 4))])
+def test_grouped_conv_bundles_and_residual_vs_torch(c, groups, stride, hw):
+    """ResNeXt's grouped 3x3 as channel bundles (bts_conv_desc.n_bundles), BN+ReLU epilogue; then a 1x1 with the
+    residual-add epilogue (bts_conv_desc.res) -- against F.conv2d(groups=...) / explicit add in fp64 on the CPU."""
+    import torch.nn.functional as F
+    from bts_amd import ops
+    h, w = hw
+    B = 2
+    gen = torch.Generator().manual_seed(c + stride)
+    x = torch.randn(B, c, h, w, generator=gen)
+    wt = torch.randn(c, c // groups, 3, 3, generator=gen) / np.sqrt(9 * c // groups)
+    sc, sh = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen) * 0.1
+    ref = F.relu(F.conv2d(x.double(), wt.double(), stride=stride, padding=1, groups=groups) * sc.double().view(1, -1, 1, 1)
+                 + sh.double().view(1, -1, 1, 1))
+    ho, wo = ref.shape[2:]
+    wp, nb, cb = ops.pack_grouped_conv_weight(wt.cuda(), groups)
+    x2d = x.cuda().permute(0, 2, 3, 1).reshape(B * h * w, c).contiguous()
+    y = torch.empty(B * ho * wo, c, device="cuda")
+    ops.conv_forward(x2d, B, h, w, wp, cb, 3, stride=stride, pad=1, c_in_ld=cb, e1=(sc.cuda(), sh.cuda()), act=ops.ACT_RELU,
+                     y2d=y, n_bundles=nb, c_in_real=c // groups)
+    got = y.view(B, ho, wo, c).permute(0, 3, 1, 2).cpu().double()
+    assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # 1x1 + BN + residual + ReLU
+    w3 = torch.randn(64, c, 1, 1, generator=gen) / np.sqrt(c)
+    res = torch.randn(B, 64, ho, wo, generator=gen)
+    ref3 = F.relu(F.conv2d(ref, w3.double()) * 0.7 + 0.1 + res.double())
+    w3p, co3, _ = ops.pack_conv_weight(w3.cuda())
+    e3 = (torch.full((co3,), 0.7, device="cuda"), torch.full((co3,), 0.1, device="cuda"))
+    res2d = res.cuda().permute(0, 2, 3, 1).reshape(B * ho * wo, 64).contiguous()
+    y3 = torch.empty(B * ho * wo, 64, device="cuda")
+    ops.conv_forward(y, B, ho, wo, w3p, 64, 1, e1=e3, act=ops.ACT_RELU, y2d=y3, res2d=res2d)
+    got3 = y3.view(B, ho, wo, 64).permute(0, 3, 1, 2).cpu().double()
+    assert (got3 - ref3).abs().max().item() <= 5e-5 * ref3.abs().max().item()
+
+
+@pytest.mark.parametrize("enc,shape", [("resnet50_bts", (2, 64, 96)), ("resnext50_bts", (1, 96, 64)),
+                                       ("resnext101_bts", (2, 64, 96))])
+def test_resnet_hip_taps_vs_torch_cpu(enc, shape):
+    """ResNet / ResNeXt encoders on the HIP conv kernel (residual epilogue, grouped bundles) vs the same nn modules
+    on the CPU: the reference's tap list [x, relu, layer1..layer4] (bts.py:318-338)."""
+    from bts_amd import bts as M
+    from bts_amd.encoder_hip import ResNetHip
+    torch.manual_seed(3)
+    e = M.encoder(Params(enc, 512, 80.0, "kitti")).eval()
+    _randomise_bn(e, 5)
+    B, H, W = shape
+    x = torch.from_numpy(synth.image_batch(B, H, W, 21))
+    with torch.no_grad():
+        ref = e(x)
+    eg = M.encoder(Params(enc, 512, 80.0, "kitti")).eval()
+    eg.load_state_dict(e.state_dict())
+    eg = eg.cuda()
+    plan = ResNetHip(eg.base_model)
+    with torch.no_grad():
+        got = plan.taps_nchw(x.cuda())
+    assert len(got) == len(ref) == 6
+    for i in range(1, 6):
+        r, g = ref[i], got[i].cpu()
+        assert r.shape == g.shape
+        scale = r.abs().max().item()
+        err = (r - g).abs().max().item()
+        assert err <= 3e-4 * scale + 1e-5, "tap %d: max abs err %g (scale %g)" % (i, err, scale)
+
+
+def test_btsmodel_resnext101_fused_forward_vs_cpu():
+    """BASELINE config 3's model (ResNeXt101 plan, NYU head): BtsModel.forward all on HIP == CPU torch encoder + oracle."""
+    from bts_amd import bts as M
+    params = Params("resnext101_bts", 512, 10.0, "nyu")
+    torch.manual_seed(12)
+    model = M.BtsModel(params).eval()
+    _randomise_bn(model.encoder, 8)
+    feat = synth.ENCODER_CHANNELS[params.encoder]
+    state_np = synth.decoder_state(feat, 512, 0)
+    model.decoder.load_state_dict({k: (torch.tensor(v) if np.ndim(v) == 0 else torch.from_numpy(v.copy())) for k, v in state_np.items()})
+    B, H, W = 2, 64, 96
+    x = torch.from_numpy(synth.image_batch(B, H, W, 6))
+    focal = torch.from_numpy(synth.focal_values(B, "nyu", 6))
+    with torch.no_grad():
+        ref_outs, inter = O.decoder_forward(O.state_from_numpy(state_np), model.encoder(x), focal, 10.0, "nyu",
+                                            want_intermediates=True)
+    mg = M.BtsModel(params).eval()
+    mg.load_state_dict(model.state_dict())
+    mg = mg.cuda()
+    with torch.no_grad():
+        got = mg(x.cuda(), focal.cuda())
+    assert mg._enc_hip is not None and type(mg._enc_hip).__name__ == "ResNetHip"
+    rep = check_outputs(got, ref_outs, inter, rel_tol=5e-4, what="fused ResNeXt101 BtsModel")
+    print("fused ResNeXt101 model max-rel:", rep)

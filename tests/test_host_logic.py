@@ -24,12 +24,12 @@ def test_cabi_exports_every_declared_symbol():
     from bts_amd import _lib
     assert set(_lib.SYMBOLS) == declared
     lib.bts_hip_abi_version.restype = ctypes.c_int
-    assert lib.bts_hip_abi_version() == 1
+    assert lib.bts_hip_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_conv_desc_layout_matches_header():
     from bts_amd._lib import ConvDesc
-    assert ctypes.sizeof(ConvDesc) == 192
+    assert ctypes.sizeof(ConvDesc) == 216
     assert ConvDesc.w.offset == 56 and ConvDesc.y.offset == 136 and ConvDesc.y_nchw.offset == 152
 
 
