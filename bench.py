@@ -143,6 +143,15 @@ def cpu_baseline(params, H, W, seconds_budget=15.0, gpu_frame0=None):
     return out, parity
 
 
+def baseline_config_label(enc, B, H, W):
+    """Which BASELINE.json configuration a run corresponds to (the metric is quoted on configs[1])."""
+    if (enc, B, H, W) == ("densenet161_bts", 16, 352, 1216):
+        return " (BASELINE.json configs[1])"
+    if (enc, B, H, W) == ("resnext101_bts", 16, 416, 544):
+        return " (BASELINE.json configs[2], not the headline configuration)"
+    return " (not a BASELINE.json configuration)"
+
+
 def main():
     # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL does at init) are
     # sent to stderr for the whole run; the JSON goes to the saved descriptor at the end
@@ -157,6 +166,8 @@ def main():
     ap.add_argument("--height", type=int, default=352)
     ap.add_argument("--width", type=int, default=1216)
     ap.add_argument("--encoder", default="densenet161_bts")
+    ap.add_argument("--dataset", choices=["kitti", "nyu"], default="kitti",
+                    help="decoder head: kitti (max_depth 80, focal scaling) or nyu (max_depth 10), bts.py:289-291")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step all-gather of the 5 depth maps (N>1)")
@@ -188,7 +199,7 @@ def main():
     torch.backends.cudnn.enabled = args.encoder_backend == "miopen"
 
     from bts_amd import dist as bdist, ops, synth
-    is_kitti = True
+    is_kitti = args.dataset == "kitti"
     params = Params(args.encoder, 512, 80.0 if is_kitti else 10.0, "kitti" if is_kitti else "nyu")
     B, H, W = args.batch, args.height, args.width
     log("building model %s" % args.encoder)
@@ -349,7 +360,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("BTS decoder hot path only" if args.decoder_only else "BtsModel.forward (encoder+decoder)")
-                       + ", %s, B=%d per GPU, 3x%dx%d fp32 (BASELINE.json configs[1])" % (args.encoder, B, H, W),
+                       + ", %s, B=%d per GPU, 3x%dx%d fp32%s" % (args.encoder, B, H, W, baseline_config_label(args.encoder, B, H, W)),
                        "batch_per_gpu": B, "global_batch": B * world, "image": "%dx%d" % (H, W),
                        "parallelism": "dp%d batch-sharded, RCCL weight broadcast once%s" % (
                            world, ", all-gather of 5 depth maps per step" if gather else ""),

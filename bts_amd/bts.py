@@ -527,10 +527,10 @@ class encoder(nn.Module):
 class BtsModel(nn.Module):
     """bts.py:341-349.  Same constructor and forward signature.
 
-    With a DenseNet encoder, eval mode and a GPU input the whole forward is native: the encoder runs on
-    the HIP conv kernel (bts_amd.encoder_hip) writing its taps straight into the decoder's NHWC concat
-    buffers.  Other encoders (ResNet/ResNeXt) run on PyTorch-ROCm as in the reference and hand NCHW taps
-    to the HIP decoder."""
+    In eval mode with a GPU input the whole forward is native: the encoder (DenseNet-121/161, ResNet-50/101,
+    ResNeXt-50/101) runs on the HIP conv kernel (bts_amd.encoder_hip) writing its taps straight into the decoder's
+    NHWC concat buffers.  ``native_encoder = False`` runs the torch encoder modules instead (NCHW taps handed to the
+    HIP decoder).  train() mode: see bts_amd/train.py."""
 
     def __init__(self, params):
         super(BtsModel, self).__init__()

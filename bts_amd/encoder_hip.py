@@ -1,4 +1,4 @@
-"""DenseNet encoder on the HIP conv kernel (NHWC, no MIOpen).
+"""DenseNet and ResNet/ResNeXt encoders on the HIP conv kernel (NHWC, no MIOpen): ``DenseNetHip``, ``ResNetHip``.
 
 The reference encoder is torchvision's DenseNet walked tap by tap (reference pytorch/bts.py:295-338);
 it is the caller side of the decoder hot path.  This image has no MIOpen find-db for gfx950 (a first
