@@ -211,8 +211,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     const int tiles_all = a.tiles_per_class * a.n_classes;
     const int split = swz / tiles_all;
     const int srem = swz - split * tiles_all;
-    const int cls = srem / a.tiles_per_class;
-    const int tcl = srem - cls * a.tiles_per_class;
+    // sub-pixel: class-minor order -- the four parity classes of one source tile run back to back, so the source pixels
+    // they all gather are fetched from HBM once and re-read from L2 (class-major order re-fetched them 4x, PMC);
+    // bundles (disjoint channels) stay bundle-major
+    const int cls = a.subpix ? (srem & 3) : srem / a.tiles_per_class;
+    const int tcl = a.subpix ? (srem >> 2) : srem - cls * a.tiles_per_class;
     const int mt_idx = tcl / a.n_ntiles, nt_idx = tcl % a.n_ntiles;
     const long m0 = (long)mt_idx * BM;
     const int n0 = nt_idx * BN;
