@@ -46,7 +46,7 @@ class ConvWgradDesc(C.Structure):
         ("dy", C.c_void_p), ("dy_pix_stride", C.c_long), ("c_out", C.c_int),
         ("B", C.c_int), ("h_in", C.c_int), ("w_in", C.c_int),
         ("up", C.c_int), ("ksize", C.c_int), ("dil", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
-        ("dw", C.c_void_p), ("ws", C.c_void_p), ("ws_floats", C.c_long),
+        ("dw", C.c_void_p), ("ws", C.c_void_p), ("ws_floats", C.c_long), ("n_bundles", C.c_int),
     ]
 
 

@@ -559,9 +559,11 @@ class BtsModel(nn.Module):
         return dec.forward_nhwc(ws, B, H, W, focal, r["dense"], r["norm5"], r["norm5"] is not None, outs=outs)
 
     def forward(self, x, focal):
-        if self.training and self.native_encoder and 'densenet' in self.encoder.params.encoder \
-                and isinstance(x, torch.Tensor) and x.is_cuda:
-            return self.decoder(train.densenet_encoder_forward(self.encoder, x), focal)    # training step on HIP convs
+        if self.training and self.native_encoder and isinstance(x, torch.Tensor) and x.is_cuda:
+            # training step: encoder + decoder as one autograd graph on the HIP kernels (bts_amd/train.py)
+            enc_fwd = train.resnet_encoder_forward if isinstance(self.encoder.base_model, encoders.ResNet) \
+                else train.densenet_encoder_forward
+            return self.decoder(enc_fwd(self.encoder, x), focal)
         if not self._native_ok(x):
             skip_feat = self.encoder(x)
             return self.decoder(skip_feat, focal)

@@ -28,6 +28,8 @@ struct WgradArgs {
     unsigned M;                  // B*H*W output pixels
     unsigned pix_per_split;      // multiple of WBK
     int n_ntiles;
+    int n_bundles;               // grouped convolution as channel bundles (blockIdx.z): bundle j uses input channels
+                                 // [j*c_in, ..), gradient channels [j*c_out, ..) and writes dense block j of [c_out][N]
 };
 
 // One workgroup = 4 waves arranged WM x WN over a BM x BN tile of dw; each wave owns (BM/WM) x (BN/WN).
@@ -50,6 +52,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     const int l31 = lane & 31, khalf = lane >> 5;
     const int tile_n = blockIdx.x % a.n_ntiles, tile_m = blockIdx.x / a.n_ntiles;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const float* __restrict__ xg = a.x + (size_t)blockIdx.z * a.c_in;      // this bundle's channel slice
+    const float* __restrict__ dyg = a.dy + (size_t)blockIdx.z * a.c_out;
 
     // ---- loader roles (fixed for the whole K walk) ----
     const int a_col = (tid % ACOLS) * 4, a_row = tid / ACOLS;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         for (int p = 0; p < PA; ++p) {
             const unsigned pix = base + a_row + p * AROWS;
             const bool ok = a_ok && pix < k_end;
-            const float* src = a.dy + (size_t)(ok ? pix : 0u) * a.dy_pix_stride + a_m;
+            const float* src = dyg + (size_t)(ok ? pix : 0u) * a.dy_pix_stride + a_m;
             f32x4 v = *reinterpret_cast<const f32x4*>(src);
             ra[p] = ok ? v : (f32x4)(0.f);
         }
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
             const int iy = py[p] * a.stride + off_y, ix = px[p] * a.stride + off_x;
             const bool ok = b_ok && pix < k_end && iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws;
             const int sb = ok ? pb[p] : 0, sy = ok ? (iy >> a.ups) : 0, sx = ok ? (ix >> a.ups) : 0;
-            const float* src = a.x + ((size_t)(sb * a.h_in + sy) * a.w_in + sx) * a.x_pix_stride + ci;
+            const float* src = xg + ((size_t)(sb * a.h_in + sy) * a.w_in + sx) * a.x_pix_stride + ci;
             f32x4 v = *reinterpret_cast<const f32x4*>(src);
             rb[p] = ok ? v : (f32x4)(0.f);
             // advance this row's output pixel by one K-step without dividing (issue() is called for it = 0, 1, 2, ...)
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     }
 
     // ---- store: D register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31 ----
-    float* out = a.out + (size_t)blockIdx.y * a.c_out * a.N;
+    float* out = a.out + ((size_t)blockIdx.y * a.n_bundles + blockIdx.z) * a.c_out * a.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -206,7 +210,7 @@ int launch_wgrad(WgradArgs a, long split, float* dw, float* ws, hipStream_t s) {
     const int m_tiles = (a.c_out + BM - 1) / BM;
     a.n_ntiles = (a.N + BN - 1) / BN;
     const long tiles = (long)m_tiles * a.n_ntiles;
-    const long per = (long)a.c_out * a.N;
+    const long per = (long)a.c_out * a.N * a.n_bundles;
     long pps = (((long)a.M + split - 1) / split + WBK - 1) / WBK * WBK;
     split = ((long)a.M + pps - 1) / pps;                         // no empty splits
     a.pix_per_split = (unsigned)pps;
@@ -219,7 +223,7 @@ int launch_wgrad(WgradArgs a, long split, float* dw, float* ws, hipStream_t s) {
             return (int)hipGetLastError();
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)split), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)split, (unsigned)a.n_bundles), dim3(256), lds_bytes, s, a);
     if (split > 1) {
         const long count4 = per / 4;      // N % 4 == 0
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count4 + 15) / 16)), dim3(256), 0, s, ws, dw, count4,
@@ -235,11 +239,11 @@ int launch_wgrad(WgradArgs a, long split, float* dw, float* ws, hipStream_t s) {
 // with the split chosen to reach ~768 workgroups within [>= 4 K-steps per split, <= 1024 splits, workspace size].
 struct WgradPlan { int variant; long split; };
 
-inline WgradPlan plan_wgrad(int c_out, int N, long M, long ws_floats, bool have_ws) {
+inline WgradPlan plan_wgrad(int c_out, int N, long M, long ws_floats, bool have_ws, int n_bundles) {
     static const int bm[4] = {128, 64, 32, 64}, bn[4] = {128, 128, 128, 64};
     static const double eff[4] = {1.0, 0.9, 0.75, 0.8};
     static const long target = getenv("BTS_WGRAD_TARGET") ? atol(getenv("BTS_WGRAD_TARGET")) : 768;
-    const long per = (long)c_out * N;
+    const long per = (long)c_out * N * n_bundles;
     long max_split = M / (4 * WBK);
     if (max_split > 1024) max_split = 1024;
     if (!have_ws || ws_floats < 2 * per) max_split = 1;
@@ -250,7 +254,7 @@ inline WgradPlan plan_wgrad(int c_out, int N, long M, long ws_floats, bool have_
     double best_score = -1.0;
     for (int v = 0; v < 4; ++v) {
         const long mt = (c_out + bm[v] - 1) / bm[v], nt = (N + bn[v] - 1) / bn[v];
-        const long tiles = mt * nt;
+        const long tiles = mt * nt * n_bundles;
         long split = (target + tiles - 1) / tiles;
         if (split > max_split) split = max_split;
         const double useful = (double)c_out * N / ((double)mt * bm[v] * nt * bn[v]);
@@ -296,7 +300,10 @@ extern "C" int bts_conv_wgrad_f32(const bts_conv_wgrad_desc* d, bts_stream_t str
     a.N = d->ksize * d->ksize * d->c_in;
     a.pix_per_split = 0; a.n_ntiles = 0;
     hipStream_t s = (hipStream_t)stream;
-    const WgradPlan p = plan_wgrad(d->c_out, a.N, (long)a.M, d->ws_floats, d->ws != nullptr);
+    a.n_bundles = d->n_bundles > 1 ? d->n_bundles : 1;
+    if (d->n_bundles < 0 || a.n_bundles > 65535) return BTS_ERR_INVALID;
+    if (d->x_pix_stride < (long)a.n_bundles * d->c_in || d->dy_pix_stride < (long)a.n_bundles * d->c_out) return BTS_ERR_INVALID;
+    const WgradPlan p = plan_wgrad(d->c_out, a.N, (long)a.M, d->ws_floats, d->ws != nullptr, a.n_bundles);
     switch (p.variant) {
         case 0: return launch_wgrad<128, 128, 2, 2>(a, p.split, d->dw, d->ws, s);
         case 1: return launch_wgrad<64, 128, 1, 4>(a, p.split, d->dw, d->ws, s);
@@ -319,6 +326,10 @@ struct PackEntry {          // 12 x int64, filled by the host (bts_amd/train.py)
     long s_row, s_c;        // element strides in src for the packed row / inner channel
     long flip;              // 0: taps as stored, 1: spatially flipped (input gradient)
     long first_block;       // prefix sum of blocks over the table
+    long cg, gmode;         // grouped weight [C][cg][k][k] packed block-diagonally into a bundle (src points at the
+                            // bundle's first output channel): cg = channels per group; gmode 1 = forward (row = output
+                            // channel, inner = bundle-local input channel), 2 = input gradient (row = bundle-local input
+                            // channel, inner = output channel); entries outside a row's own group are zero.  0 = dense
 };
 
 constexpr int PACK_PER_BLOCK = 256 * 4 * 4;
@@ -346,7 +357,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __re
                 const long tap = col / e.c_in_ld, c = col - tap * e.c_in_ld;
                 if (tap < kk2 && c < e.inner) {
                     const long t = e.flip ? kk2 - 1 - tap : tap;
-                    v[j] = e.src[row * e.s_row + c * e.s_c + t];
+                    if (e.gmode == 0) {
+                        v[j] = e.src[row * e.s_row + c * e.s_c + t];
+                    } else if (row / e.cg == c / e.cg) {                 // same group: the only non-zero block
+                        const long g0 = (row / e.cg) * e.cg;
+                        const long r = e.gmode == 2 ? row - g0 : row, cc = e.gmode == 1 ? c - g0 : c;
+                        v[j] = e.src[r * e.s_row + cc * e.s_c + t];
+                    }
                 }
             }
         }

@@ -466,23 +466,26 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
 
 def conv_wgrad(x2d: torch.Tensor, B: int, h_in: int, w_in: int, c_in: int, dy2d: torch.Tensor, c_out: int,
                ksize: int, dil: int = 1, stride: int = 1, pad: Optional[int] = None, up: int = 1,
-               ws: Optional[torch.Tensor] = None, tag: str = "wgrad") -> torch.Tensor:
+               ws: Optional[torch.Tensor] = None, tag: str = "wgrad", n_bundles: int = 1) -> torch.Tensor:
     """Weight gradient of one bias-free convolution (bts_conv_wgrad_f32): returns dw as [c_out, ksize*ksize, c_in]
     (OHWI).  x2d: [B*h_in*w_in, >=c_in] NHWC view of the forward input, dy2d: [B*H*W, >=c_out] NHWC view of the
-    output gradient; c_in and c_out multiples of 4 (pad with zero channels)."""
+    output gradient; c_in and c_out multiples of 4 (pad with zero channels).  ``n_bundles`` > 1: grouped convolution
+    as channel bundles (c_in / c_out per bundle): returns the dense blocks [n_bundles, c_out, ksize*ksize, c_in]."""
     xs, xc = _rows2d(x2d, "conv_wgrad")
     ds, dc = _rows2d(dy2d, "conv_wgrad")
     if pad is None:
         pad = dil * (ksize // 2)
     H = (h_in * up + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
     W = (w_in * up + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
-    if c_in % 4 or c_out % 4 or c_in > xc or c_out > dc:
+    if c_in % 4 or c_out % 4 or c_in * n_bundles > xc or c_out * n_bundles > dc:
         raise BtsHipError("conv_wgrad: c_in/c_out must be multiples of 4 within the views (%d/%d, %d/%d)" % (c_in, xc, c_out, dc))
     if x2d.shape[0] != B * h_in * w_in or dy2d.shape[0] != B * H * W:
         raise BtsHipError("conv_wgrad: views %s / %s do not match B=%d %dx%d -> %dx%d"
                           % (tuple(x2d.shape), tuple(dy2d.shape), B, h_in, w_in, H, W))
-    dw = torch.empty((c_out, ksize * ksize, c_in), dtype=torch.float32, device=x2d.device)
+    shape = (c_out, ksize * ksize, c_in) if n_bundles <= 1 else (n_bundles, c_out, ksize * ksize, c_in)
+    dw = torch.empty(shape, dtype=torch.float32, device=x2d.device)
     d = ConvWgradDesc()
+    d.n_bundles = n_bundles if n_bundles > 1 else 0
     d.x, d.x_pix_stride, d.c_in = x2d.data_ptr(), xs, c_in
     d.dy, d.dy_pix_stride, d.c_out = dy2d.data_ptr(), ds, c_out
     d.B, d.h_in, d.w_in, d.up, d.ksize, d.dil, d.stride, d.pad = B, h_in, w_in, up, ksize, dil, stride, pad
@@ -491,8 +494,8 @@ def conv_wgrad(x2d: torch.Tensor, B: int, h_in: int, w_in: int, c_in: int, dy2d:
         _need(ws, "conv_wgrad")
         d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
     taps = ksize * ksize
-    flops = 2.0 * B * H * W * c_out * c_in * taps
-    nbytes = 4.0 * (B * h_in * w_in * c_in + B * H * W * c_out + taps * c_out * c_in)
+    flops = 2.0 * B * H * W * c_out * c_in * taps * max(n_bundles, 1)
+    nbytes = 4.0 * (B * h_in * w_in * c_in + B * H * W * c_out + taps * c_out * c_in) * max(n_bundles, 1)
     with torch.cuda.device(x2d.device):
         rc = _launch("conv_wgrad_kernel", tag, flops, nbytes, lambda: _lib.load().bts_conv_wgrad_f32(C.byref(d), _stream(x2d)))
     _lib.check(rc, "bts_conv_wgrad_f32")

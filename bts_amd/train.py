@@ -75,59 +75,87 @@ class WeightPacker:
     FWD, DGRAD = 0, 1
 
     def __init__(self):
-        self.entries = {}          # (data_ptr, shape, c_in_ld, mode) -> dict(weight, dst, version, geometry)
+        self.entries = {}          # (data_ptr, shape, c_in_ld, mode, groups) -> dict(wref, dst, version, rows)
         self._table = None
         self._table_key = None
 
     @staticmethod
-    def _geometry(weight, c_in_ld, mode):
-        cout, cin, k, _ = weight.shape
+    def bundle_channels(weight, groups):
+        """Channels per bundle for a grouped weight [C, C/groups, k, k]: consecutive groups packed block-diagonally
+        into bundles of max(32, C/groups) channels (ops.pack_grouped_conv_weight uses the same rule)."""
+        c, cg = weight.shape[0], weight.shape[1]
+        cb = max(32, cg)
+        if groups * cg != c or cb % cg or c % cb or cb % 32:
+            raise BtsHipError("train.conv2d: grouped convolution %s with %d groups is not built" % (tuple(weight.shape), groups))
+        return cb
+
+    @staticmethod
+    def _rows(weight, c_in_ld, mode, groups):
+        """Table rows (without pointers) + destination shape for one weight: one row for a dense convolution, one per
+        channel bundle for a grouped one.  Row = (src offset, dst offset, rows, inner, k, c_in_ld, rows_pad, k_pad,
+        s_row, s_c, flip, cg, gmode)."""
+        cout, cin_g, k, _ = weight.shape
+        kk = k * k
+        if groups == 1:
+            if mode == WeightPacker.FWD:
+                rows, inner, s_row, s_c, flip = cout, cin_g, cin_g * kk, kk, 0
+            else:
+                rows, inner, s_row, s_c, flip = cin_g, cout, kk, cin_g * kk, 1
+            rows_pad, k_pad = ops.round_up(rows, 32), ops.round_up(kk * c_in_ld, 32)
+            return [(0, 0, rows, inner, k, c_in_ld, rows_pad, k_pad, s_row, s_c, flip, 0, 0)], (rows_pad, k_pad)
+        cb = WeightPacker.bundle_channels(weight, groups)
+        if c_in_ld != cb:
+            raise BtsHipError("train.conv2d: grouped convolutions are packed with c_in_ld = bundle width")
+        nb, k_pad = cout // cb, kk * cb
         if mode == WeightPacker.FWD:
-            rows, inner, s_row, s_c, flip = cout, cin, cin * k * k, k * k, 0
+            s_row, s_c, flip, gmode = cin_g * kk, kk, 0, 1
         else:
-            rows, inner, s_row, s_c, flip = cin, cout, k * k, cin * k * k, 1
-        rows_pad = ops.round_up(rows, 32)
-        k_pad = ops.round_up(k * k * c_in_ld, 32)
-        return rows, inner, k, c_in_ld, rows_pad, k_pad, s_row, s_c, flip
+            s_row, s_c, flip, gmode = kk, cin_g * kk, 1, 2
+        rows = [(j * cb * cin_g * kk, j * cb * k_pad, cb, cb, k, cb, cb, k_pad, s_row, s_c, flip, cin_g, gmode)
+                for j in range(nb)]
+        return rows, (nb, cb, k_pad)
 
     def _table_for(self, items):
         import numpy as np
         from . import _lib
         lib = _lib.load()
-        rows, first = [], 0
+        table, first = [], 0
         for e in items:
-            g = e["geom"]
-            rows.append([e["ptr"], e["dst"].data_ptr(), g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], first])
-            first += int(lib.bts_pack_weights_blocks(g[4], g[5]))
-        return torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(items[0]["dst"].device), first
+            src, dst = e["ptr"], e["dst"].data_ptr()
+            for (so, do, rows, inner, k, cld, rows_pad, k_pad, s_row, s_c, flip, cg, gmode) in e["rows"]:
+                table.append([src + 4 * so, dst + 4 * do, rows, inner, k, cld, rows_pad, k_pad, s_row, s_c, flip, first,
+                              cg, gmode])
+                first += int(lib.bts_pack_weights_blocks(rows_pad, k_pad))
+        return torch.from_numpy(np.asarray(table, dtype=np.int64)).to(items[0]["dst"].device), first, len(table)
 
-    def _launch(self, items, table, blocks):
+    def _launch(self, items, table, blocks, n_rows):
         from . import _lib
         dev = items[0]["dst"].device
         with torch.cuda.device(dev):
             rc = ops._launch("pack_weights_kernel", "pack", 0.0, 0.0,
-                             lambda: _lib.load().bts_pack_weights_f32(table.data_ptr(), len(items), blocks,
+                             lambda: _lib.load().bts_pack_weights_f32(table.data_ptr(), n_rows, blocks,
                                                                       torch.cuda.current_stream(dev).cuda_stream))
         _lib.check(rc, "bts_pack_weights_f32")
         for e in items:
             e["version"] = e["wref"]()._version
 
-    def get(self, weight, c_in_ld, mode):
-        """Packed buffer for ``weight`` (an nn.Parameter or any contiguous OIHW CUDA tensor), current with its values."""
-        key = (weight.data_ptr(), tuple(weight.shape), c_in_ld, mode)
+    def get(self, weight, c_in_ld, mode, groups=1):
+        """Packed buffer for ``weight`` (an nn.Parameter or any contiguous OIHW CUDA tensor), current with its values:
+        [rows_pad, k_pad] for a dense convolution, [n_bundles, cb, k_pad] for a grouped one."""
+        key = (weight.data_ptr(), tuple(weight.shape), c_in_ld, mode, groups)
         e = self.entries.get(key)
         if e is not None and e["wref"]() is None:          # the tensor this entry was packed from is gone: the address
             e = None                                        # now belongs to someone else's values
         if e is None:
             if not weight.is_contiguous():
                 raise BtsHipError("train.conv2d: weight must be contiguous OIHW")
-            g = self._geometry(weight, c_in_ld, mode)
-            e = self.entries[key] = dict(wref=weakref.ref(weight), ptr=weight.data_ptr(), geom=g, version=-1,
-                                         dst=torch.empty((g[4], g[5]), dtype=torch.float32, device=weight.device))
+            rows, shape = self._rows(weight, c_in_ld, mode, groups)
+            e = self.entries[key] = dict(wref=weakref.ref(weight), ptr=weight.data_ptr(), rows=rows, version=-1,
+                                         dst=torch.empty(shape, dtype=torch.float32, device=weight.device))
             self._table_key = None
         if e["version"] != e["wref"]()._version:
-            table, blocks = self._table_for([e])
-            self._launch([e], table, blocks)
+            table, blocks, n_rows = self._table_for([e])
+            self._launch([e], table, blocks, n_rows)
         return e["dst"]
 
     def refresh(self):
@@ -140,9 +168,9 @@ class WeightPacker:
             return
         key = tuple(id(e) for e in stale)
         if self._table_key != key:                        # the usual case after step 1: the same full set every step
-            self._table, self._table_blocks = self._table_for(stale)
+            self._table, self._table_blocks, self._table_rows = self._table_for(stale)
             self._table_key = key
-        self._launch(stale, self._table, self._table_blocks)
+        self._launch(stale, self._table, self._table_blocks, self._table_rows)
 
 
 _PACKER = WeightPacker()
@@ -154,61 +182,96 @@ def begin_step():
 
 
 class _ConvFn(torch.autograd.Function):
-    """y = conv2d(nearest_up(x, up), w, stride, padding, dilation), bias-free, on libbts_hip.so."""
+    """y = conv2d(nearest_up(x, up), w, stride, padding, dilation, groups), bias-free, on libbts_hip.so."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, dilation, up, tag):
+    def forward(ctx, x, weight, stride, padding, dilation, up, tag, groups):
         ops._need(x, "train.conv2d")
         ops._need(weight, "train.conv2d")
         B, C, h, w = x.shape
-        cout, cin, k, k2 = weight.shape
-        if cin != C or k != k2:
-            raise BtsHipError("train.conv2d: weight %s does not fit input %s" % (tuple(weight.shape), tuple(x.shape)))
+        cout, cin_g, k, k2 = weight.shape
+        if cin_g * groups != C or k != k2:
+            raise BtsHipError("train.conv2d: weight %s (groups %d) does not fit input %s"
+                              % (tuple(weight.shape), groups, tuple(x.shape)))
         x2d, c4 = _nhwc_rows(x.detach())
-        wp = _PACKER.get(weight, c4, WeightPacker.FWD)
         H = (h * up + 2 * padding - dilation * (k - 1) - 1) // stride + 1
         W = (w * up + 2 * padding - dilation * (k - 1) - 1) // stride + 1
         y = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
-        ops.conv_forward(x2d, B, h, w, wp, cout, k, dil=dilation, up=up, c_in_ld=c4, y2d=y.view(B * H * W, cout),
-                         stride=stride, pad=padding, tag=tag + ".fwd", c_in_real=C, splitk_ws=_splitk_workspace(x.device))
+        if groups > 1:
+            if up != 1 or cout != C:
+                raise BtsHipError("train.conv2d: grouped convolutions need cin == cout and no upsample")
+            cb = WeightPacker.bundle_channels(weight, groups)
+            wp = _PACKER.get(weight, cb, WeightPacker.FWD, groups)
+            ops.conv_forward(x2d, B, h, w, wp, cb, k, dil=dilation, c_in_ld=cb, y2d=y.view(B * H * W, cout), stride=stride,
+                             pad=padding, tag=tag + ".fwd", c_in_real=cin_g, n_bundles=C // cb)
+        else:
+            wp = _PACKER.get(weight, c4, WeightPacker.FWD)
+            ops.conv_forward(x2d, B, h, w, wp, cout, k, dil=dilation, up=up, c_in_ld=c4, y2d=y.view(B * H * W, cout),
+                             stride=stride, pad=padding, tag=tag + ".fwd", c_in_real=C,
+                             splitk_ws=_splitk_workspace(x.device))
         ctx.save_for_backward(x2d)
         ctx.weight = weight                   # the caller's parameter object: the packer tracks it by identity/version
-        ctx.geom = (B, C, h, w, c4, cout, k, stride, padding, dilation, up, H, W, tag)
+        ctx.geom = (B, C, h, w, c4, cout, k, stride, padding, dilation, up, H, W, tag, groups)
         return y.permute(0, 3, 1, 2)          # [B,cout,H,W] channels_last view
 
     @staticmethod
     def backward(ctx, grad_out):
         x2d, = ctx.saved_tensors
         weight = ctx.weight
-        B, C, h, w, c4, cout, k, stride, padding, dilation, up, H, W, tag = ctx.geom
+        B, C, h, w, c4, cout, k, stride, padding, dilation, up, H, W, tag, groups = ctx.geom
         dy2d, co4 = _nhwc_rows(grad_out)
+        dev = grad_out.device
         dx = dw = None
         if ctx.needs_input_grad[0]:
             pad_t = dilation * (k - 1) - padding
-            if stride != 1 or pad_t < 0:
-                raise BtsHipError("train.conv2d: input gradient is built for stride-1 convolutions with "
-                                  "padding <= dilation*(k-1) (every convolution of the BTS decoder and DenseNet "
-                                  "body); got stride %d padding %d" % (stride, padding))
-            wp = _PACKER.get(weight, co4, WeightPacker.DGRAD)            # flipped, transposed kernel [cin][taps*co4]
+            if stride not in (1, 2) or pad_t < 0 or (stride == 2 and up != 1):
+                raise BtsHipError("train.conv2d: input gradient is built for stride 1 or 2 with padding <= "
+                                  "dilation*(k-1); got stride %d padding %d" % (stride, padding))
             Hs, Ws = h * up, w * up
-            dxu = torch.empty((B, Hs, Ws, C), dtype=torch.float32, device=grad_out.device)
-            ops.conv_forward(dy2d, B, H, W, wp, C, k, dil=dilation, c_in_ld=co4, y2d=dxu.view(B * Hs * Ws, C),
-                             pad=pad_t, tag=tag + ".dgrad", c_in_real=cout, splitk_ws=_splitk_workspace(grad_out.device))
+            g2d, gh, gw = dy2d, H, W
+            if stride == 2:
+                # adjoint of the stride: the gradient sits on the even positions of a zero map of the input's size, and
+                # the stride-1 adjoint below runs on that (4x the FLOPs of the handful of strided layers, exact)
+                u = torch.zeros((B, Hs, Ws, co4), dtype=torch.float32, device=dev)
+                u[:, 0:2 * H:2, 0:2 * W:2] = dy2d.view(B, H, W, co4)
+                g2d, gh, gw = u.view(B * Hs * Ws, co4), Hs, Ws
+            dxu = torch.empty((B, Hs, Ws, C), dtype=torch.float32, device=dev)
+            if groups > 1:
+                cb = WeightPacker.bundle_channels(weight, groups)
+                wp = _PACKER.get(weight, cb, WeightPacker.DGRAD, groups)
+                ops.conv_forward(g2d, B, gh, gw, wp, cb, k, dil=dilation, c_in_ld=cb, y2d=dxu.view(B * Hs * Ws, C),
+                                 pad=pad_t, tag=tag + ".dgrad", c_in_real=weight.shape[1], n_bundles=C // cb)
+            else:
+                wp = _PACKER.get(weight, co4, WeightPacker.DGRAD)        # flipped, transposed kernel [cin][taps*co4]
+                ops.conv_forward(g2d, B, gh, gw, wp, C, k, dil=dilation, c_in_ld=co4, y2d=dxu.view(B * Hs * Ws, C),
+                                 pad=pad_t, tag=tag + ".dgrad", c_in_real=cout, splitk_ws=_splitk_workspace(dev))
             if up == 2:                                                 # adjoint of the nearest-2x upsample
                 dxu = dxu.view(B, h, 2, w, 2, C).sum(dim=(2, 4))
             dx = dxu.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            g = ops.conv_wgrad(x2d, B, h, w, c4, dy2d, co4, k, dil=dilation, stride=stride, pad=padding, up=up,
-                               ws=_workspace(grad_out.device), tag=tag + ".wgrad")
-            dw = g[:cout, :, :C].reshape(cout, k, k, C).permute(0, 3, 1, 2)
-        return dx, dw, None, None, None, None, None
+            if groups > 1:
+                cb = WeightPacker.bundle_channels(weight, groups)
+                cg, nb = weight.shape[1], C // cb
+                gpb = cb // cg
+                g = ops.conv_wgrad(x2d, B, h, w, cb, dy2d, cb, k, dil=dilation, stride=stride, pad=padding,
+                                   ws=_workspace(dev), tag=tag + ".wgrad", n_bundles=nb)   # [nb, cb, taps, cb] dense blocks
+                g6 = g.view(nb, gpb, cg, k * k, gpb, cg)
+                idx = torch.arange(gpb, device=dev)
+                diag = g6[:, idx, :, :, idx, :]                         # [gpb, nb, cg_out, taps, cg_in]: each group's own block
+                dw = diag.permute(1, 0, 2, 4, 3).reshape(cout, cg, k, k)
+            else:
+                g = ops.conv_wgrad(x2d, B, h, w, c4, dy2d, co4, k, dil=dilation, stride=stride, pad=padding, up=up,
+                                   ws=_workspace(dev), tag=tag + ".wgrad")
+                dw = g[:cout, :, :C].reshape(cout, k, k, C).permute(0, 3, 1, 2)
+        return dx, dw, None, None, None, None, None, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, padding: int = 0, dilation: int = 1, stride: int = 1,
-           up: int = 1, tag: str = "conv") -> torch.Tensor:
+           up: int = 1, tag: str = "conv", groups: int = 1) -> torch.Tensor:
     """Differentiable bias-free convolution on the HIP kernels; ``up=2`` folds a nearest-2x upsample of ``x`` into
-    the gather (reference upconv, bts.py:90-92).  Returns a channels_last [B,c_out,H,W] tensor."""
-    return _ConvFn.apply(x, weight, stride, padding, dilation, up, tag)
+    the gather (reference upconv, bts.py:90-92); ``groups`` > 1: ResNeXt's grouped 3x3 as channel bundles.
+    Returns a channels_last [B,c_out,H,W] tensor."""
+    return _ConvFn.apply(x, weight, stride, padding, dilation, up, tag, groups)
 
 
 _BN_WS: Dict[Tuple[str, int], torch.Tensor] = {}
@@ -395,4 +458,37 @@ def densenet_encoder_forward(enc, x):
     cur = x.float().contiguous(memory_format=torch.channels_last)
     _run_children(list(enc.base_model.named_children()), cur,
                   tapped=lambda name: any(fragment in name for fragment in enc.feat_names), taps=taps)
+    return taps
+
+
+# ------------------------------------------------------------------------------------------ encoder (ResNet / ResNeXt)
+def _bottleneck(blk, x, tag):
+    """torchvision Bottleneck.forward: 1x1 -> (grouped, strided) 3x3 -> 1x1, + identity, ReLU."""
+    out = _bn(conv2d(x, blk.conv1.weight, tag=tag), blk.bn1, relu=True)
+    c2 = blk.conv2
+    out = _bn(conv2d(out, c2.weight, padding=c2.padding[0], dilation=c2.dilation[0], stride=c2.stride[0], groups=c2.groups,
+                     tag=tag), blk.bn2, relu=True)
+    out = _bn(conv2d(out, blk.conv3.weight, tag=tag), blk.bn3)
+    if blk.downsample is not None:
+        d = blk.downsample[0]
+        x = _bn(conv2d(x, d.weight, stride=d.stride[0], tag=tag), blk.downsample[1])
+    return F.relu(out + x)
+
+
+def resnet_encoder_forward(enc, x):
+    """encoder.forward (bts.py:327-338) for the ResNet-50/101 and ResNeXt-50/101 encoders in train() mode: taps
+    [x, relu, layer1, layer2, layer3, layer4]; every convolution (incl. the grouped and strided ones) and norm layer and
+    their gradients on libbts_hip.so, max-pool / residual add on PyTorch-ROCm kernels."""
+    ops._need(x, "train.encoder")
+    begin_step()
+    m = enc.base_model
+    cur = x.float().contiguous(memory_format=torch.channels_last)
+    c1 = m.conv1
+    cur = _bn(conv2d(cur, c1.weight, padding=c1.padding[0], stride=c1.stride[0], tag="enc"), m.bn1, relu=True)
+    taps = [x, cur]
+    cur = m.maxpool(cur)
+    for li, layer in enumerate((m.layer1, m.layer2, m.layer3, m.layer4)):
+        for blk in layer:
+            cur = _bottleneck(blk, cur, "enc")
+        taps.append(cur)
     return taps

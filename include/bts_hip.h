@@ -181,16 +181,22 @@ typedef struct bts_conv_wgrad_desc {
     float* dw;              /* [c_out][ksize*ksize][c_in]                                                */
     float* ws;              /* NULL or scratch, exclusive to this stream while the call runs             */
     long  ws_floats;
+    int   n_bundles;        /* 0/1: ordinary.  > 1: grouped convolution as channel bundles (see bts_conv_desc):
+                               c_in / c_out are PER BUNDLE, bundle j uses x channels [j*c_in, ..) and dy channels
+                               [j*c_out, ..); dw = [n_bundles][c_out][ksize*ksize][c_in] dense blocks, of which the
+                               caller keeps each group's diagonal block                                            */
 } bts_conv_wgrad_desc;
 
 int bts_conv_wgrad_f32(const bts_conv_wgrad_desc* desc, bts_stream_t stream);
 
 /* Batched weight re-packing for the training step (the optimiser rewrites the OIHW parameters every iteration,
  * bts_main.py:606): one launch lays every registered weight out as bts_conv_fwd_f32 wants it.
- * table: n_entries device records of 12 int64 each --
+ * table: n_entries device records of 14 int64 each --
  *   { src (OIHW float*), dst (float* [rows_pad][k_pad]), rows, inner, ksize, c_in_ld, rows_pad, k_pad,
  *     s_row, s_c (element strides of packed row / inner channel in src), flip (1 = spatially flipped taps),
- *     first_block (prefix sum of bts_pack_weights_blocks over the table) }
+ *     first_block (prefix sum of bts_pack_weights_blocks over the table),
+ *     cg, gmode (grouped weights packed block-diagonally per bundle: channels per group and 1 = forward /
+ *     2 = input-gradient layout; 0, 0 for dense weights) }
  *   forward layout : rows = c_out, inner = c_in, s_row = c_in*k*k, s_c = k*k, flip 0
  *   input gradient : rows = c_in, inner = c_out, s_row = k*k, s_c = c_in*k*k, flip 1   (transposed, flipped kernel)
  * dst[row][tap*c_in_ld + c] = src[row*s_row + c*s_c + (flip ? k*k-1-tap : tap)], zero elsewhere.

@@ -66,6 +66,42 @@ def test_conv2d_gradients_vs_torch_cpu(case):
         close(xd.grad, x64.grad, "input grad")
 
 
+GROUPED_CASES = [
+    # B, cin, cout, h, w, k, pad, stride, groups
+    (2, 128, 128, 10, 14, 3, 1, 1, 32),        # resnext50 layer1: 4 channels per group (8 groups per 32-channel bundle)
+    (2, 256, 256, 10, 14, 3, 1, 2, 32),        # 8 per group, strided (first block of a stage)
+    (2, 512, 512, 6, 8, 3, 1, 1, 32),          # 16 per group
+    (1, 1024, 1024, 6, 8, 3, 1, 2, 32),        # 32 per group = one group per bundle, strided
+    (1, 2048, 2048, 3, 4, 3, 1, 1, 32),        # 64 per group (64-channel bundles)
+    (2, 128, 128, 10, 14, 3, 1, 2, 1),         # resnet50 conv2, dense, strided
+    (2, 256, 512, 10, 14, 1, 0, 2, 1),         # downsample 1x1 stride 2
+]
+
+
+@pytest.mark.parametrize("case", GROUPED_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_grouped_and_strided_conv_gradients_vs_torch_cpu(case):
+    """ResNet / ResNeXt bottleneck convolutions in the training graph: channel-bundled grouped 3x3 (forward, input and
+    weight gradient) and the stride-2 input gradient (zero-inserted adjoint) vs torch autograd in fp64."""
+    from bts_amd import train
+    B, cin, cout, h, w, k, pad, stride, groups = case
+    gen = torch.Generator().manual_seed(cin + 13 * stride + groups)
+    x = torch.randn(B, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin // groups, k, k, generator=gen) / np.sqrt(cin // groups * k * k)
+    x64, w64 = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    y_ref = F.conv2d(x64, w64, stride=stride, padding=pad, groups=groups)
+    gy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(gy.double())
+    xd, wd = x.cuda().requires_grad_(True), wt.cuda().requires_grad_(True)
+    y = train.conv2d(xd, wd, padding=pad, stride=stride, groups=groups)
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    y.backward(gy.cuda())
+    torch.cuda.synchronize()
+    for got, ref, what in ((y.detach(), y_ref.detach(), "forward"), (wd.grad, w64.grad, "weight grad"), (xd.grad, x64.grad, "input grad")):
+        scale = ref.abs().max().item()
+        err = (got.cpu().double() - ref).abs().max().item()
+        assert err <= 5e-5 * scale, (what, err, scale)
+
+
 def test_wgrad_split_is_deterministic_and_matches_unsplit():
     """The pixel split only regroups a sum: with and without workspace agree to fp32 rounding, and two runs of the
     split path are bit-identical (fixed-order reduction, no atomics)."""
@@ -339,3 +375,48 @@ def test_decoder_train_step_full_training_crop_vs_oracle():
     # fp32 against fp32 (both sides carry their own rounding / ReLU-mask flips; per-tensor maxima over up to 10 M
     # elements): per-tensor bars are loose, the global relative L2 -- measured 3.3e-4 -- is the tight one
     assert_grads_close(per, l2, "352x704 decoder step", typical=1e-2, worst=0.2, l2=2e-3)
+
+
+def test_btsmodel_train_step_resnext50_vs_cpu():
+    """Whole-model training step with a ResNeXt encoder (grouped + strided convolutions in the graph) vs the CPU:
+    torch encoder modules + oracle decoder, fp64 yardstick and the fp32 CPU run as the noise floor."""
+    import copy
+    from bts_amd import bts as M
+    params = Params("resnext50_bts", 512, 10.0, "nyu")
+    torch.manual_seed(31)
+    model = M.BtsModel(params).train()
+    B, H, W = 2, 64, 96
+    x = torch.from_numpy(synth.image_batch(B, H, W, 15))
+    focal = torch.from_numpy(synth.focal_values(B, "nyu", 15))
+    gt, mask = synth.train_targets(B, H, W, 10.0, 19)
+
+    def cpu_step(dtype):
+        enc = copy.deepcopy(model.encoder).to(dtype)
+        state = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone())
+                 for k, v in model.decoder.state_dict().items()}
+        for k, v in state.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        outs = O.decoder_forward(state, enc(x.to(dtype)), focal.to(dtype), 10.0, "nyu", training=True)
+        loss = O.silog_loss(outs[4], t(gt).to(dtype), t(mask), 0.85)
+        loss.backward()
+        grads = {"encoder." + n: p.grad for n, p in enc.named_parameters() if p.grad is not None}
+        grads.update({"decoder." + n: v.grad for n, v in state.items() if v.requires_grad})
+        return loss.item(), grads
+
+    loss64, g64 = cpu_step(torch.float64)
+    loss32, g32 = cpu_step(torch.float32)
+    mg = model.cuda()
+    outs = mg(x.cuda(), focal.cuda())
+    loss = M.silog_loss(0.85)(outs[4], t(gt).cuda(), t(mask).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss64) <= max(2e-4 * abs(loss64), 4 * abs(loss32 - loss64)), (loss.item(), loss64, loss32)
+    got = {n: p.grad.cpu().numpy() for n, p in mg.named_parameters() if p.grad is not None}
+    assert set(got) == set(g64), set(got) ^ set(g64)          # the unused fc head gets no gradient on either side
+    ref = {n: v.numpy() for n, v in g64.items()}
+    per, l2 = grad_error_report(got, ref)
+    per32, l2_32 = grad_error_report({n: v.numpy() for n, v in g32.items()}, ref)
+    print("ResNeXt50 whole-model step, global rel-L2 vs fp64: hip %.2e, cpu fp32 %.2e; worst tensor hip %.2e, cpu fp32 %.2e"
+          % (l2, l2_32, max(per.values()), max(per32.values())))
+    assert_grads_close(per, l2, "resnext50 whole model / fp64", fp32_floor=(per32, l2_32))
