@@ -19,7 +19,7 @@ SYMBOLS = (
     "bts_pack_weights_blocks", "bts_pack_weights_f32",
 )
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConvDesc(C.Structure):
@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("y", C.c_void_p), ("y_pix_stride", C.c_long), ("y_nchw", C.c_int),
         ("subpixel", C.c_int), ("y2", C.c_void_p), ("y2_pix_stride", C.c_long),
         ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_long),
-        ("res", C.c_void_p), ("res_pix_stride", C.c_long), ("n_bundles", C.c_int),
+        ("res", C.c_void_p), ("res_pix_stride", C.c_long), ("n_bundles", C.c_int), ("precision", C.c_int),
     ]
 
 

@@ -169,10 +169,68 @@ __device__ __forceinline__ void stage_to_lds(const ConvArgs& a, float* __restric
             *reinterpret_cast<f32x4*>(Bs + (p * RPP + lrow) * LDS_LD + lk) = rb[p];
 }
 
+// ---- "fp32 on the bf16 matrix cores" (bts_conv_desc.precision = 1) ---------------------------------------------
+// Each fp32 operand x is split on the way to LDS into three bf16 pieces h + m + l (truncation split: h = top 16 bits
+// of x, m = top 16 bits of x - h, l = top 16 bits of x - h - m; the subtractions are exact), stored as three bf16
+// planes; a 32x32 block of the product then takes six v_mfma_f32_32x32x16_bf16 per 16 k (hh, hm, mh, hl, lh, mm --
+// the three dropped cross terms are below 2^-24 of the product), accumulated in fp32.  Products of bf16 pairs are
+// exact in fp32, so the only roundings are the fp32 accumulation (as in the fp32-MFMA path, but 8x fewer partial
+// sums) and the 2^-24-relative tail of the split: measured error 6e-7 of max|result| on K = 2304 dot products vs
+// 1.2e-6 for the v_mfma_f32_32x32x2_f32 chain.  The bf16 pipe runs 16x the fp32-MFMA rate, six products cost 6/16.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int EMU_ROW_BYTES = 80;             // 32 bf16 of one K-step + 16 B pad: b128 fragment reads conflict-free
+
+__device__ __forceinline__ void split_store(char* plane0, int plane_bytes, int byte_off, const f32x4 v) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned xb = __float_as_uint(v[i]);
+        h[i] = xb & 0xffff0000u;
+        const float r = v[i] - __uint_as_float(h[i]);
+        m[i] = __float_as_uint(r) & 0xffff0000u;
+        l[i] = __float_as_uint(r - __uint_as_float(m[i])) & 0xffff0000u;
+    }
+    // bf16 pairs: low half = element 2i, high half = element 2i+1
+    u32x2 ph = {__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+    u32x2 pm = {__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+    u32x2 pl = {__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+    *reinterpret_cast<u32x2*>(plane0 + byte_off) = ph;
+    *reinterpret_cast<u32x2*>(plane0 + plane_bytes + byte_off) = pm;
+    *reinterpret_cast<u32x2*>(plane0 + 2 * plane_bytes + byte_off) = pl;
+}
+
+// same role as stage_to_lds: prologue + zero padding, then the split into the three bf16 planes of one LDS buffer
+// (layout [plane][A rows BM | B rows BN][EMU_ROW_BYTES])
+template <int BM, int BN, int RPP, int PA, int PB>
+__device__ __forceinline__ void stage_to_lds_emu(const ConvArgs& a, char* __restrict__ buf, int lrow, int lk,
+                                                 const f32x4 (&ra)[PA], const f32x4 (&rb)[PB], const f32x4& ps,
+                                                 const f32x4& pb, unsigned okmask) {
+    constexpr int PLANE = (BM + BN) * EMU_ROW_BYTES;
+    const bool has_pre = a.pre_scale != nullptr;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        f32x4 v = ra[p];
+        if (has_pre) v = v * ps + pb;
+        if (a.pre_relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        const bool ok = (okmask >> p) & 1u;
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        split_store(buf, PLANE, (p * RPP + lrow) * EMU_ROW_BYTES + lk * 2, v);
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+        if ((p + 1) * RPP <= BN || p * RPP + lrow < BN)
+            split_store(buf, PLANE, (BM + p * RPP + lrow) * EMU_ROW_BYTES + lk * 2, rb[p]);
+}
+
 // MF = 32: v_mfma_f32_32x32x2_f32 tiles (default).  MF = 16: v_mfma_f32_16x16x4_f32 tiles, same FLOP rate
 // but 16-column granularity -- used for c_out = 48 (DenseNet growth) where a 64-wide tile wastes 25 %.
-template <int BM, int BN, int WM, int WN, int MF, bool NCHW_OUT>
+template <int BM, int BN, int WM, int WN, int MF, bool NCHW_OUT, int PREC = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a0) {
+    static_assert(PREC == 0 || MF == 32, "the bf16x3 emulation uses the 32x32x16 bf16 MFMA");
     constexpr int NT = WM * WN * 64;          // threads per workgroup (4 or 8 waves)
     constexpr int RPP = NT / 8;               // tile rows staged per pass (8 lanes x 16 B per row)
     constexpr int TM = BM / WM / MF, TN = BN / WN / MF;
@@ -185,7 +243,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     // layout: [buf][A rows BM | B rows BN][LDS_LD]
-    constexpr int BUF_FLOATS = (BM + BN) * LDS_LD;
+    constexpr int BUF_FLOATS = PREC == 0 ? (BM + BN) * LDS_LD : 3 * (BM + BN) * EMU_ROW_BYTES / 4;
 
     // XCD-aware block remap (bijective): blocks sharing an XCD (bid % 8) get a contiguous range of
     // tiles, so neighbouring pixel tiles (shared halo rows) and the N tiles of one M tile share an L2.
@@ -302,53 +360,100 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
             issue_loads<PA, PB>(a, wbase, pad_y, pad_x, it0 + t, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
         }
     };
+    auto stage = [&](float* dst) __attribute__((always_inline)) {
+        if constexpr (PREC == 0) stage_to_lds<BM, BN, RPP, PA, PB, LDS_LD>(a, dst, lrow, lk, ra, rb, ps, pb, okmask);
+        else stage_to_lds_emu<BM, BN, RPP, PA, PB>(a, reinterpret_cast<char*>(dst), lrow, lk, ra, rb, ps, pb, okmask);
+    };
     issue(0);
-    stage_to_lds<BM, BN, RPP, PA, PB, LDS_LD>(a, smem, lrow, lk, ra, rb, ps, pb, okmask);
+    stage(smem);
     if (nit > 1) issue(1);
     __syncthreads();
 
-    constexpr int KG = 256 / MF;              // k covered by one ds_read_b128 per lane set: 8 (MF 32) / 16 (MF 16)
-    constexpr int NG = BK / KG;               // fragment groups per K-step: 4 / 2
-    const int a_off = (wm * TM * MF + li) * LDS_LD + 4 * lh;
-    const int b_off = BM * LDS_LD + (wn * TN * MF + li) * LDS_LD + 4 * lh;
-    // Fragments are double-buffered in registers: group g+1 is read from LDS while group g's MFMAs issue, and
-    // the first group of the NEXT K-step is read right after the barrier.
-    f32x4 fa[2][TM], fb[2][TN];
-    auto read_frags = [&](const float* base, int g, int slot) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(base + a_off + i * MF * LDS_LD + KG * g);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4*>(base + b_off + j * MF * LDS_LD + KG * g);
-    };
-    read_frags(smem, 0, 0);
+    if constexpr (PREC == 0) {
+        constexpr int KG = 256 / MF;              // k covered by one ds_read_b128 per lane set: 8 (MF 32) / 16 (MF 16)
+        constexpr int NG = BK / KG;               // fragment groups per K-step: 4 / 2
+        const int a_off = (wm * TM * MF + li) * LDS_LD + 4 * lh;
+        const int b_off = BM * LDS_LD + (wn * TN * MF + li) * LDS_LD + 4 * lh;
+        // Fragments are double-buffered in registers: group g+1 is read from LDS while group g's MFMAs issue, and
+        // the first group of the NEXT K-step is read right after the barrier.
+        f32x4 fa[2][TM], fb[2][TN];
+        auto read_frags = [&](const float* base, int g, int slot) {
+    #pragma unroll
+            for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(base + a_off + i * MF * LDS_LD + KG * g);
+    #pragma unroll
+            for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4*>(base + b_off + j * MF * LDS_LD + KG * g);
+        };
+        read_frags(smem, 0, 0);
 
-    for (int it = 0; it < nit; ++it) {
-        const int buf = it & 1;
-        const float* cur = smem + buf * BUF_FLOATS;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) read_frags(cur, g + 1, (g + 1) & 1);
-            // q outermost: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        // NCHW_OUT: rows = channels, lanes = pixels; else rows = pixels, lanes = channels
-                        const float ra_ = NCHW_OUT ? fb[g & 1][j][q] : fa[g & 1][i][q];
-                        const float rb_ = NCHW_OUT ? fa[g & 1][i][q] : fb[g & 1][j][q];
-                        if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_, rb_, acc[i][j], 0, 0, 0);
-                        else                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra_, rb_, acc[i][j], 0, 0, 0);
-                    }
-            if (g == 0) {     // after the first MFMA group: the staging VALU / ds_writes / address math issue in the
-                              // shadow of the remaining groups; the new loads still get ~a full step to land
-                if (it + 1 < nit) stage_to_lds<BM, BN, RPP, PA, PB, LDS_LD>(a, smem + (buf ^ 1) * BUF_FLOATS, lrow, lk, ra, rb, ps, pb, okmask);
-                if (it + 2 < nit) issue(it + 2);
+        for (int it = 0; it < nit; ++it) {
+            const int buf = it & 1;
+            const float* cur = smem + buf * BUF_FLOATS;
+    #pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) read_frags(cur, g + 1, (g + 1) & 1);
+                // q outermost: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
+    #pragma unroll
+                for (int q = 0; q < 4; ++q)
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            // NCHW_OUT: rows = channels, lanes = pixels; else rows = pixels, lanes = channels
+                            const float ra_ = NCHW_OUT ? fb[g & 1][j][q] : fa[g & 1][i][q];
+                            const float rb_ = NCHW_OUT ? fa[g & 1][i][q] : fb[g & 1][j][q];
+                            if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_, rb_, acc[i][j], 0, 0, 0);
+                            else                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra_, rb_, acc[i][j], 0, 0, 0);
+                        }
+                if (g == 0) {     // after the first MFMA group: the staging VALU / ds_writes / address math issue in the
+                                  // shadow of the remaining groups; the new loads still get ~a full step to land
+                    if (it + 1 < nit) stage(smem + (buf ^ 1) * BUF_FLOATS);
+                    if (it + 2 < nit) issue(it + 2);
+                }
             }
+            __syncthreads();
+            if (it + 1 < nit) read_frags(smem + (buf ^ 1) * BUF_FLOATS, 0, 0);
         }
-        __syncthreads();
-        if (it + 1 < nit) read_frags(smem + (buf ^ 1) * BUF_FLOATS, 0, 0);
+    } else {
+        // bf16x3: per k16 step every 32x32 block takes six bf16 MFMAs on the (h, m, l) planes
+        constexpr int PLANE = (BM + BN) * EMU_ROW_BYTES;
+        const int a_byte = (wm * TM * 32 + li) * EMU_ROW_BYTES + lh * 16;
+        const int b_byte = (BM + wn * TN * 32 + li) * EMU_ROW_BYTES + lh * 16;
+        for (int it = 0; it < nit; ++it) {
+            const int buf = it & 1;
+            const char* cur = reinterpret_cast<const char*>(smem + buf * BUF_FLOATS);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 fa[3][TM], fb[3][TN];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[pl][i] = *reinterpret_cast<const u32x4*>(cur + pl * PLANE + a_byte + i * 32 * EMU_ROW_BYTES + ks * 32);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        fb[pl][j] = *reinterpret_cast<const u32x4*>(cur + pl * PLANE + b_byte + j * 32 * EMU_ROW_BYTES + ks * 32);
+                }
+                // product order hh, hm, mh, hl, lh, mm; the pair index outermost so consecutive MFMAs hit different
+                // accumulators
+                constexpr int PA_[6] = {0, 0, 1, 0, 2, 1}, PB_[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const u32x4 xa = NCHW_OUT ? fb[PB_[t]][j] : fa[PA_[t]][i];
+                            const u32x4 xb = NCHW_OUT ? fa[PA_[t]][i] : fb[PB_[t]][j];
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xa),
+                                                                                __builtin_bit_cast(bf16x8, xb), acc[i][j], 0, 0, 0);
+                        }
+                if (ks == 0) {
+                    if (it + 1 < nit) stage(smem + (buf ^ 1) * BUF_FLOATS);
+                    if (it + 2 < nit) issue(it + 2);
+                }
+            }
+            __syncthreads();
+        }
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -444,7 +549,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, in
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MF = 32>
+template <int BM, int BN, int WM, int WN, int MF = 32, int PREC = 0>
 int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     ConvArgs a = a0;
     const long n_mtiles = (a.M + BM - 1) / BM;
@@ -474,21 +579,22 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     }
     const long nwg = tiles * a.ksplit;
     if (nwg > 0x7fffffffL) return BTS_ERR_INVALID;
-    size_t lds = (size_t)2 * (BM + BN) * LdsLd<MF>::value * sizeof(float);
+    size_t lds = PREC == 0 ? (size_t)2 * (BM + BN) * LdsLd<MF>::value * sizeof(float)
+                           : (size_t)2 * 3 * (BM + BN) * EMU_ROW_BYTES;
     if (const char* f = getenv("BTS_CONV_LDS_KB")) {   // tuning aid: inflate LDS to limit workgroups per CU
         const size_t v = (size_t)atoi(f) * 1024;
         if (v > lds && v <= 160 * 1024) lds = v;
     }
     hipError_t e;
     if (nchw) {
-        auto k = conv_fwd_kernel<BM, BN, WM, WN, MF, true>;
+        auto k = conv_fwd_kernel<BM, BN, WM, WN, MF, true, PREC>;
         if (lds > 64 * 1024) {
             e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, a);
     } else {
-        auto k = conv_fwd_kernel<BM, BN, WM, WN, MF, false>;
+        auto k = conv_fwd_kernel<BM, BN, WM, WN, MF, false, PREC>;
         if (lds > 64 * 1024) {
             e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
@@ -600,6 +706,17 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     const bool nchw = d->y_nchw != 0;
     int bm, bn;
     choose_tile(a.M * a.n_classes, d->c_out, &bm, &bn);
+    // precision: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products), 1 = fp32 emulated on the bf16 matrix cores
+    // (three-way split, six products; see split_store).  BTS_CONV_PRECISION overrides the descriptor (A/B runs).
+    static const int prec_env = getenv("BTS_CONV_PRECISION") ? atoi(getenv("BTS_CONV_PRECISION")) : -1;
+    const int prec = prec_env >= 0 ? prec_env : d->precision;
+    if (prec != 0 && prec != 1) return BTS_ERR_INVALID;
+    if (prec == 1) {
+        if (bn == 48) bn = 64;                       // the 16x16x4 48-wide tile has no bf16x3 twin: pad to 64
+        if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4, 32, 1>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 4, 32, 1>(a, nchw, s, wsf);
+        if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2, 32, 1>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2, 32, 1>(a, nchw, s, wsf);
+        return launch_conv<128, 32, 4, 1, 32, 1>(a, nchw, s, wsf);
+    }
     if (bn == 48) return bm == 128 ? launch_conv<128, 48, 4, 1, 16>(a, nchw, s, wsf) : launch_conv<64, 48, 4, 1, 16>(a, nchw, s, wsf);
     // 8-wave workgroups (two waves per SIMD from the same tile) for the 128-row tiles: +2 % end to end over the
     // 4-wave layout on MI355X (more waves to cover each other's staging); BTS_CONV_W8=0 selects the 4-wave kernels

@@ -352,6 +352,19 @@ def bn_affine(weight, bias, mean, var, eps: float):
     return scale, shift
 
 
+# conv precision for every conv_forward call: 0 = fp32-input MFMA (default), 1 = fp32 emulated on the bf16 matrix
+# cores (bts_conv_desc.precision); set_conv_precision() switches the whole model, e.g. for an A/B bench
+_conv_precision = 0
+
+
+def set_conv_precision(mode) -> int:
+    """'fp32' / 0 or 'bf16x3' / 1; returns the previous mode."""
+    global _conv_precision
+    prev = _conv_precision
+    _conv_precision = {"fp32": 0, "bf16x3": 1, 0: 0, 1: 1}[mode]
+    return prev
+
+
 def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torch.Tensor, c_out: int,
                  ksize: int, dil: int = 1, up: int = 1, c_in_ld: Optional[int] = None,
                  pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_relu: bool = False,
@@ -404,6 +417,7 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     d.w, d.c_out, d.c_out_pad = w_packed.data_ptr(), c_out, c_out_pad
     keep = []
     d.n_bundles = n_bundles if n_bundles > 1 else 0
+    d.precision = _conv_precision
     for name, pair, n in (("pre", pre, c_in_ld * n_bundles), ("e1", e1, c_out_pad * n_bundles), ("e2", e2, c_out_pad * n_bundles)):
         if pair is not None:
             s, b = pair

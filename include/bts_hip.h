@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 2
+#define BTS_HIP_ABI_VERSION 3
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -149,6 +149,11 @@ typedef struct bts_conv_desc {
                                 w = [n_bundles][c_out_pad][k_pad]; pre_* hold n_bundles*c_in_ld and e1_/e2_*
                                 n_bundles*c_out_pad entries; x_pix_stride >= n_bundles*c_in_ld,
                                 y_pix_stride >= n_bundles*c_out; no sub-pixel, NCHW output or split-K               */
+    int   precision;         /* 0: fp32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation).
+                                1: fp32 EMULATED on the bf16 matrix cores -- every operand split into three bf16
+                                pieces on the way to LDS, six bf16 MFMAs per product block, fp32 accumulation; the
+                                result differs from mode 0 only by fp32 rounding (measured 6e-7 vs 1.2e-6 of
+                                max|result| against fp64), at up to 2.6x the MFMA rate.  Same inputs, outputs, tiles. */
 } bts_conv_desc;
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);

@@ -146,3 +146,74 @@ def test_module_level_forwards(decoders):
         xu = torch.from_numpy(rng.standard_normal(size=(1, 128, 5, 7), dtype=np.float32))
         torch.testing.assert_close(dec.upconv3(xu.cuda()).cpu(), O.upconv_forward(xu, state["upconv3.conv.weight"]),
                                    rtol=1e-4, atol=2e-5)
+
+
+EMU_CONV_CASES = [
+    # B, cin, cout, h, w, k, dil, stride, up/subpixel, nchw_out
+    (2, 256, 128, 11, 19, 3, 6, 1, "plain", False),       # ASPP dilated 3x3
+    (2, 576, 256, 11, 19, 1, 1, 1, "plain", False),       # ASPP 1x1
+    (1, 228, 128, 12, 20, 3, 1, 1, "plain", False),       # odd channel count (general loader)
+    (2, 36, 32, 16, 24, 3, 1, 1, "plain", True),          # conv1: NCHW output
+    (2, 64, 32, 8, 12, 3, 1, 1, "subpixel", False),       # sub-pixel upconv
+    (2, 4, 96, 32, 48, 7, 1, 2, "plain", False),          # stem: stride 2, 7x7
+    (1, 2208, 512, 2, 3, 3, 1, 1, "subpixel", False),     # upconv5: K = 8832 per class
+]
+
+
+@pytest.mark.parametrize("case", EMU_CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf16x3_emulation_is_fp32_accurate(case):
+    """bts_conv_desc.precision = 1 (fp32 emulated on the bf16 matrix cores: three-way operand split, six products)
+    against fp64 torch on the CPU, beside the fp32-MFMA mode on the same inputs: both must sit at fp32 rounding level,
+    and the emulation may not be more than 3x further from exact than the fp32 MFMA chain."""
+    import torch.nn.functional as F
+    from bts_amd import ops
+    B, cin, cout, h, w, k, dil, stride, mode, nchw = case
+    gen = torch.Generator().manual_seed(cin * 3 + cout)
+    x = torch.randn(B, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, k, k, generator=gen) / np.sqrt(cin * k * k)
+    pad = dil * (k // 2)
+    xin = F.interpolate(x.double(), scale_factor=2, mode="nearest") if mode == "subpixel" else x.double()
+    ref = F.elu(F.conv2d(xin, wt.double(), stride=stride, padding=pad, dilation=dil))
+    H, W = ref.shape[2:]
+    c4 = (cin + 3) // 4 * 4
+    x2d = torch.zeros(B * h * w, c4, device="cuda")
+    x2d[:, :cin] = x.cuda().permute(0, 2, 3, 1).reshape(B * h * w, cin)
+    if mode == "subpixel":
+        wp, _, _ = ops.pack_upconv_subpixel(wt.cuda(), c_in_ld=c4)
+    else:
+        wp, _, _ = ops.pack_conv_weight(wt.cuda(), c_in_ld=c4)
+    errs = {}
+    for prec in ("fp32", "bf16x3"):
+        prev = ops.set_conv_precision(prec)
+        try:
+            if nchw:
+                y = torch.empty(B, cout, H, W, device="cuda")
+                ops.conv_forward(x2d, B, h, w, wp, cout, k, dil=dil, stride=stride, pad=pad, c_in_ld=c4, act=ops.ACT_ELU,
+                                 y_nchw=y, c_in_real=cin)
+                got = y.cpu().double()
+            else:
+                y = torch.empty(B * H * W, cout, device="cuda")
+                ops.conv_forward(x2d, B, h, w, wp, cout, 3 if mode == "subpixel" else k, dil=dil, stride=stride,
+                                 pad=pad if mode != "subpixel" else None, up=2 if mode == "subpixel" else 1, c_in_ld=c4,
+                                 act=ops.ACT_ELU, y2d=y, subpixel=(mode == "subpixel"), c_in_real=cin)
+                got = y.view(B, H, W, cout).permute(0, 3, 1, 2).cpu().double()
+        finally:
+            ops.set_conv_precision(prev)
+        errs[prec] = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(case, errs)
+    assert errs["fp32"] <= 1e-5 and errs["bf16x3"] <= 1e-5, errs
+    assert errs["bf16x3"] <= 3.0 * errs["fp32"] + 2e-7, errs
+
+
+@pytest.mark.parametrize("cname", ["K", "N"])
+def test_decoder_bf16x3_mode_vs_oracle(decoders, cname):
+    """The whole decoder with every convolution in the bf16x3-emulated mode: same parity bar as the default path."""
+    from bts_amd import ops
+    ref_outs, inter = oracle_run(cname, 2, 64, 96, 4321)
+    prev = ops.set_conv_precision("bf16x3")
+    try:
+        got = hip_run(decoders[cname], cname, 2, 64, 96, 4321)
+    finally:
+        ops.set_conv_precision(prev)
+    rep = check_outputs(got, ref_outs, inter, what=cname + " small / bf16x3")
+    print(cname, "bf16x3 max-rel:", rep)
