@@ -88,7 +88,7 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(params, H, W, seconds_budget=15.0, gpu_frame0=None):
+def cpu_baseline(params, H, W, seconds_budget=15.0, gpu_frame0=None, extra_frame0=None):
     """The oracle (CPU restatement, oracle/bts_oracle.py) + the same torch encoder on the host cores.
     Bounded sample: B=1 frames of the same 352x1216 workload until ~seconds_budget is spent."""
     from bts_amd import bts as M, synth
@@ -103,6 +103,28 @@ def cpu_baseline(params, H, W, seconds_budget=15.0, gpu_frame0=None):
     focal = torch.from_numpy(synth.focal_values(1, params.dataset, 1234))
     times = []
     parity = None
+    extra_parity = {}
+
+    def compare(gpu_set, outs, inter):
+        names = ("depth_8x8_scaled", "depth_4x4_scaled", "depth_2x2_scaled", "reduc1x1", "final_depth")
+        par = {"tolerance": 1e-3, "frame": 0}
+        near = 0
+        for j, nm in enumerate(names):
+            g = gpu_set[j].double().cpu().numpy()
+            r = outs[j][0:1].double().numpy()
+            mask = np.ones(r.shape, dtype=bool)
+            if j < 3:
+                k = (8, 4, 2)[j]
+                den = O.lpg_denominator(inter["plane_eq_%dx%d" % (k, k)], k).unsqueeze(1).numpy()
+                mask = np.abs(den) > 2e-3          # near the +-1e-3 clamp relative error is meaningless
+                near += int((~mask).sum())
+            par[nm] = float(np.max(np.abs(g - r)[mask] / np.maximum(np.abs(r)[mask], 1e-30)))
+        ic = np.abs(gpu_set[5].double().cpu().numpy() - outs[5][0:1].double().numpy())
+        par["iconv1_max_abs"] = float(ic.max())
+        par["near_singular_lpg_px_masked"] = near
+        par["ok"] = bool(max(par[n] for n in names) <= 1e-3)
+        return par, names
+
     with torch.no_grad():
         t_all = time.perf_counter()
         for i in range(40):
@@ -113,24 +135,11 @@ def cpu_baseline(params, H, W, seconds_budget=15.0, gpu_frame0=None):
             if i == 0 and gpu_frame0 is not None:
                 # parity gate of THIS run: frame 0 of the GPU batch (same PCG64 image, same weights) vs the CPU oracle
                 outs, inter = ref
-                names = ("depth_8x8_scaled", "depth_4x4_scaled", "depth_2x2_scaled", "reduc1x1", "final_depth")
-                parity = {"tolerance": 1e-3, "frame": 0}
-                near = 0
-                for j, nm in enumerate(names):
-                    g = gpu_frame0[j].double().cpu().numpy()
-                    r = outs[j][0:1].double().numpy()
-                    mask = np.ones(r.shape, dtype=bool)
-                    if j < 3:
-                        k = (8, 4, 2)[j]
-                        den = O.lpg_denominator(inter["plane_eq_%dx%d" % (k, k)], k).unsqueeze(1).numpy()
-                        mask = np.abs(den) > 2e-3          # near the +-1e-3 clamp relative error is meaningless
-                        near += int((~mask).sum())
-                    parity[nm] = float(np.max(np.abs(g - r)[mask] / np.maximum(np.abs(r)[mask], 1e-30)))
-                ic = np.abs(gpu_frame0[5].double().cpu().numpy() - outs[5][0:1].double().numpy())
-                parity["iconv1_max_abs"] = float(ic.max())
-                parity["near_singular_lpg_px_masked"] = near
-                parity["ok"] = bool(max(parity[n] for n in names) <= 1e-3)
+                parity, names = compare(gpu_frame0, outs, inter)
                 log("parity vs CPU oracle (frame 0): " + ", ".join("%s %.2e" % (n, parity[n]) for n in names))
+                for tag, gset in (extra_frame0 or {}).items():
+                    extra_parity[tag], _ = compare(gset, outs, inter)
+                    log("parity vs CPU oracle (frame 0, %s): " % tag + ", ".join("%s %.2e" % (n, extra_parity[tag][n]) for n in names))
             log("cpu frame %d: %.2f s" % (i, dt))
             if i > 0:
                 times.append(dt)
@@ -140,7 +149,7 @@ def cpu_baseline(params, H, W, seconds_budget=15.0, gpu_frame0=None):
     out = {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
            "sample": "B=1 x %d timed frames (1 warm-up) of the same 3x%dx%d fp32 workload, torch %s CPU encoder + "
                      "oracle decoder, median" % (len(times), H, W, torch.__version__)}
-    return out, parity
+    return out, parity, extra_parity
 
 
 def baseline_config_label(enc, B, H, W):
@@ -170,6 +179,8 @@ def main():
                     help="decoder head: kitti (max_depth 80, focal scaling) or nyu (max_depth 10), bts.py:289-291")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-emulated-leg", action="store_true",
+                    help="skip the secondary bf16x3-emulated-fp32 measurement (N=1 only; never the headline value)")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step all-gather of the 5 depth maps (N>1)")
     ap.add_argument("--streams", type=int, default=4,
                     help="run the per-GPU batch as this many concurrent sub-batches on separate HIP streams (one graph): "
@@ -368,6 +379,41 @@ def main():
                        "weights": "random-init encoder + PCG64(0) synthetic decoder"},
             "roofline": roof,
         }
+        emu = None
+        emu_frame0 = None
+        if world == 1 and not args.no_emulated_leg:
+            # Secondary measurement, NOT the headline: the same forward with every convolution in the
+            # "fp32 emulated on the bf16 matrix cores" mode (bts_conv_desc.precision = 1: three-way bf16 split of both
+            # operands, six products, fp32 accumulation -- results at fp32 rounding level, see its own parity gate).
+            prev = ops.set_conv_precision("bf16x3")
+            try:
+                with torch.no_grad():
+                    forward()
+                    torch.cuda.synchronize()
+                    g2 = None
+                    if use_graph:
+                        g2 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g2):
+                            outs2 = forward()
+                    run2 = (lambda: g2.replay()) if g2 is not None else forward
+                    for _ in range(args.warmup):
+                        run2()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        run2()
+                    torch.cuda.synchronize()
+                    el2 = time.perf_counter() - t1
+                    if not args.decoder_only:
+                        emu_frame0 = [o[0:1].clone() for o in model(image[0:1], focal[0:1])]
+                        torch.cuda.synchronize()
+                emu = {"what": "same workload, convolutions in bts_conv_desc.precision=1 (fp32 products emulated with six "
+                               "bf16 MFMAs per block after a three-way operand split, fp32 accumulate); secondary number, "
+                               "the headline `value` uses the fp32-input MFMA",
+                       "value": round(B * args.steps / el2, 3), "unit": "frames/s", "ms_per_step": round(1e3 * el2 / args.steps, 3)}
+                log("emulated-fp32 (bf16x3) leg: %.3f ms/step" % (1e3 * el2 / args.steps))
+            finally:
+                ops.set_conv_precision(prev)
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")
             frame0 = None
@@ -375,9 +421,14 @@ def main():
                 with torch.no_grad():
                     frame0 = [o[0:1].clone() for o in model(image[0:1], focal[0:1])]
                 torch.cuda.synchronize()
-            line["cpu_baseline"], par = cpu_baseline(params, H, W, gpu_frame0=frame0)
+            line["cpu_baseline"], par, xpar = cpu_baseline(params, H, W, gpu_frame0=frame0,
+                                                           extra_frame0={"bf16x3": emu_frame0} if emu_frame0 is not None else None)
             if par is not None:
                 line["parity"] = par
+            if emu is not None and "bf16x3" in xpar:
+                emu["parity"] = xpar["bf16x3"]
+        if emu is not None:
+            line["emulated_fp32_bf16x3"] = emu
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if use_dist:

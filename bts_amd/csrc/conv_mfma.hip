@@ -231,6 +231,7 @@ __device__ __forceinline__ void stage_to_lds_emu(const ConvArgs& a, char* __rest
 template <int BM, int BN, int WM, int WN, int MF, bool NCHW_OUT, int PREC = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a0) {
     static_assert(PREC == 0 || MF == 32, "the bf16x3 emulation uses the 32x32x16 bf16 MFMA");
+    static_assert(PREC >= 0 && PREC <= 2, "PREC: 0 fp32 MFMA, 1 bf16x3, 2 bf16x3 with a single LDS buffer");
     constexpr int NT = WM * WN * 64;          // threads per workgroup (4 or 8 waves)
     constexpr int RPP = NT / 8;               // tile rows staged per pass (8 lanes x 16 B per row)
     constexpr int TM = BM / WM / MF, TN = BN / WN / MF;
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     float* smem = reinterpret_cast<float*>(smem_raw);
     // layout: [buf][A rows BM | B rows BN][LDS_LD]
     constexpr int BUF_FLOATS = PREC == 0 ? (BM + BN) * LDS_LD : 3 * (BM + BN) * EMU_ROW_BYTES / 4;
+    constexpr bool EMU_SB = PREC == 2;        // bf16x3 with ONE LDS buffer (half the footprint -> two workgroups per CU)
 
     // XCD-aware block remap (bijective): blocks sharing an XCD (bid % 8) get a contiguous range of
     // tiles, so neighbouring pixel tiles (shared halo rows) and the N tiles of one M tile share an L2.
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
         const int a_byte = (wm * TM * 32 + li) * EMU_ROW_BYTES + lh * 16;
         const int b_byte = (BM + wn * TN * 32 + li) * EMU_ROW_BYTES + lh * 16;
         for (int it = 0; it < nit; ++it) {
-            const int buf = it & 1;
+            const int buf = EMU_SB ? 0 : (it & 1);
             const char* cur = reinterpret_cast<const char*>(smem + buf * BUF_FLOATS);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -447,12 +449,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xa),
                                                                                 __builtin_bit_cast(bf16x8, xb), acc[i][j], 0, 0, 0);
                         }
-                if (ks == 0) {
+                if (!EMU_SB && ks == 0) {
                     if (it + 1 < nit) stage(smem + (buf ^ 1) * BUF_FLOATS);
                     if (it + 2 < nit) issue(it + 2);
                 }
             }
             __syncthreads();
+            if (EMU_SB) {                      // everyone has read the tile: overwrite it with the next one
+                if (it + 1 < nit) stage(smem);
+                if (it + 2 < nit) issue(it + 2);
+                __syncthreads();
+            }
         }
     }
 
@@ -580,7 +587,7 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     const long nwg = tiles * a.ksplit;
     if (nwg > 0x7fffffffL) return BTS_ERR_INVALID;
     size_t lds = PREC == 0 ? (size_t)2 * (BM + BN) * LdsLd<MF>::value * sizeof(float)
-                           : (size_t)2 * 3 * (BM + BN) * EMU_ROW_BYTES;
+                           : (size_t)(PREC == 2 ? 1 : 2) * 3 * (BM + BN) * EMU_ROW_BYTES;
     if (const char* f = getenv("BTS_CONV_LDS_KB")) {   // tuning aid: inflate LDS to limit workgroups per CU
         const size_t v = (size_t)atoi(f) * 1024;
         if (v > lds && v <= 160 * 1024) lds = v;
@@ -713,6 +720,21 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if (prec != 0 && prec != 1) return BTS_ERR_INVALID;
     if (prec == 1) {
         if (bn == 48) bn = 64;                       // the 16x16x4 48-wide tile has no bf16x3 twin: pad to 64
+        // LDS buffering: the planes take 6 B per element, so the double-buffered 128x128 tile (120 KB) leaves one
+        // workgroup per CU -- best for that tile (160 vs 142 TFLOP/s-equivalent), while every narrower tile runs faster
+        // single-buffered with two workgroups per CU (conv2 112 -> 123, conv1 68 -> 82).  BTS_CONV_EMU_SB=0/1 forces.
+        static const int emu_sb_env = getenv("BTS_CONV_EMU_SB") ? atoi(getenv("BTS_CONV_EMU_SB")) : -1;
+        const int emu_sb = emu_sb_env >= 0 ? emu_sb_env : !(bm == 128 && bn == 128);
+        static const int emu_w4 = getenv("BTS_CONV_EMU_W4") ? atoi(getenv("BTS_CONV_EMU_W4")) : 0;
+        if (emu_w4 && bm == 128 && bn >= 64) {         // experiment: 4-wave workgroups with 64-row wave tiles, single buffer
+            if (bn == 128) return launch_conv<128, 128, 2, 2, 32, 2>(a, nchw, s, wsf);
+            return launch_conv<128, 64, 2, 2, 32, 2>(a, nchw, s, wsf);
+        }
+        if (emu_sb) {                                  // one LDS buffer: half the footprint, two workgroups per CU
+            if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4, 32, 2>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 4, 32, 2>(a, nchw, s, wsf);
+            if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2, 32, 2>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2, 32, 2>(a, nchw, s, wsf);
+            return launch_conv<128, 32, 4, 1, 32, 2>(a, nchw, s, wsf);
+        }
         if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4, 32, 1>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 4, 32, 1>(a, nchw, s, wsf);
         if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2, 32, 1>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2, 32, 1>(a, nchw, s, wsf);
         return launch_conv<128, 32, 4, 1, 32, 1>(a, nchw, s, wsf);
