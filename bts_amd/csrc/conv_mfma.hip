@@ -175,8 +175,8 @@ __device__ __forceinline__ void stage_to_lds(const ConvArgs& a, float* __restric
 // planes; a 32x32 block of the product then takes six v_mfma_f32_32x32x16_bf16 per 16 k (hh, hm, mh, hl, lh, mm --
 // the three dropped cross terms are below 2^-24 of the product), accumulated in fp32.  Products of bf16 pairs are
 // exact in fp32, so the only roundings are the fp32 accumulation (as in the fp32-MFMA path, but 8x fewer partial
-// sums) and the 2^-24-relative tail of the split: measured error 6e-7 of max|result| on K = 2304 dot products vs
-// 1.2e-6 for the v_mfma_f32_32x32x2_f32 chain.  The bf16 pipe runs 16x the fp32-MFMA rate, six products cost 6/16.
+// sums) and the 2^-24-relative tail of the split: measured error 1.2e-6 of max|result| on K = 2304 dot products vs
+// 1.1e-6 for the v_mfma_f32_32x32x2_f32 chain (scripts/bf16x3_numerics.py).  The bf16 pipe runs 16x the fp32-MFMA rate, six products cost 6/16.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -1,6 +1,6 @@
-// Micro-benchmark for the round-2 candidate "fp32 emulated on the bf16 matrix cores" (each fp32 operand split into
-// three bf16 pieces, six of the nine cross products kept: error 6e-7 of max|result| on K=2304 dot products, below the
-// fp32 MFMA chain's own 1.2e-6 -- see DESIGN.md section 7).  What fp32-EQUIVALENT rate does the device sustain
+// Micro-benchmark for "fp32 emulated on the bf16 matrix cores" (each fp32 operand split into
+// three bf16 pieces, six of the nine cross products kept: error 1.2e-6 of max|result| on K=2304 dot products, the same as the
+// fp32 MFMA chain's 1.1e-6 -- see DESIGN.md section 3b).  What fp32-EQUIVALENT rate does the device sustain
 //   (a) from registers only (6 x v_mfma_f32_32x32x16_bf16 per 16 k of a 32x32 block),
 //   (b) with the 12 ds_read_b128 fragment reads per k16 step of a 64x64 wave tile,
 //   (c) with (b) plus splitting one operand from fp32 on the fly (truncation split + v_perm packing)?
