@@ -723,13 +723,10 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
         // LDS buffering: the planes take 6 B per element, so the double-buffered 128x128 tile (120 KB) leaves one
         // workgroup per CU -- best for that tile (160 vs 142 TFLOP/s-equivalent), while every narrower tile runs faster
         // single-buffered with two workgroups per CU (conv2 112 -> 123, conv1 68 -> 82).  BTS_CONV_EMU_SB=0/1 forces.
+        // Tried, no gain (all land at 140-155 on the large layers): 4-wave workgroups with 64x64 wave tiles, waves
+        // spanning all 128 rows (1x4) -- the mode is bound by LDS fragment traffic (3 planes) plus staging, DESIGN 3b.
         static const int emu_sb_env = getenv("BTS_CONV_EMU_SB") ? atoi(getenv("BTS_CONV_EMU_SB")) : -1;
         const int emu_sb = emu_sb_env >= 0 ? emu_sb_env : !(bm == 128 && bn == 128);
-        static const int emu_w4 = getenv("BTS_CONV_EMU_W4") ? atoi(getenv("BTS_CONV_EMU_W4")) : 0;
-        if (emu_w4 && bm == 128 && bn >= 64) {         // experiment: 4-wave workgroups with 64-row wave tiles, single buffer
-            if (bn == 128) return launch_conv<128, 128, 2, 2, 32, 2>(a, nchw, s, wsf);
-            return launch_conv<128, 64, 2, 2, 32, 2>(a, nchw, s, wsf);
-        }
         if (emu_sb) {                                  // one LDS buffer: half the footprint, two workgroups per CU
             if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4, 32, 2>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 4, 32, 2>(a, nchw, s, wsf);
             if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2, 32, 2>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2, 32, 2>(a, nchw, s, wsf);
