@@ -303,10 +303,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
         const bool v = m < a.M;
         avalid |= (v ? 1u : 0u) << p;
         const long mm = v ? m : 0;
-        const int b = (int)(mm / HW);
-        const int yx = (int)(mm % HW);
-        ay[p] = (yx / a.W) * a.stride;
-        ax[p] = (yx % a.W) * a.stride;
+        // 32-bit unsigned divisions (the host guarantees M < 2^31): a 64-bit divide costs ~10x as many instructions, and
+        // short-K layers (K = 96..324) run only 3-11 K-steps per tile, so this prologue is not negligible there
+        const unsigned mu = (unsigned)mm;
+        const unsigned bu = mu / (unsigned)HW;
+        const unsigned yxu = mu - bu * (unsigned)HW;
+        const unsigned yu = yxu / (unsigned)a.W;
+        const int b = (int)bu;
+        ay[p] = (int)yu * a.stride;
+        ax[p] = (int)(yxu - yu * (unsigned)a.W) * a.stride;
         abase[p] = (unsigned)b * (unsigned)(a.h_in * a.w_in);
     }
     // lean-loader state: centre-pixel element offset (+ lane channel) and a tap-validity bitmask per row
@@ -511,8 +516,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
                     if (nok && m < a.M) {
                         long op = m;
                         if (a.subpix) {            // source pixel (b,Y,X) -> output pixel (b, 2Y+py, 2X+px)
-                            const int b = (int)(m / HW), yx = (int)(m % HW);
-                            const int Y = yx / a.W, X = yx - Y * a.W;
+                            const unsigned mu = (unsigned)m;
+                            const int b = (int)(mu / (unsigned)HW), yx = (int)(mu - (unsigned)b * (unsigned)HW);
+                            const int Y = (int)((unsigned)yx / (unsigned)a.W), X = yx - Y * a.W;
                             op = ((long)b * (2 * a.H) + 2 * Y + spy) * (2 * a.W) + 2 * X + spx;
                         }
                         a.y[op * a.y_pix_stride + n] = v;
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
                 const long m = m0 + (wm * TM + i) * MF + li;
                 const bool mok = m < a.M;
                 const long mm = mok ? m : 0;
-                const long b = mm / HW, yx = mm % HW;
+                const long b = (long)((unsigned)mm / (unsigned)HW), yx = (long)((unsigned)mm - (unsigned)b * (unsigned)HW);
 #pragma unroll
                 for (int r = 0; r < NACC; ++r) {
                     const int drow = MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * lh : 4 * lh + r;
@@ -699,6 +705,7 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if (a.subpix) { a.H = d->h_in; a.W = d->w_in; }      // the GEMM's M walks SOURCE pixels, per parity class
     if (a.H <= 0 || a.W <= 0) return BTS_ERR_INVALID;
     a.M = (long)d->B * a.H * a.W;
+    if (a.M >= 2147483648L) return BTS_ERR_UNSUPPORTED;          // the kernel decodes pixel indices with 32-bit arithmetic
     a.n_ntiles = 0; a.tiles_per_class = 0;
     a.n_classes = a.subpix ? 4 : 1; a.bundled = 0;
     a.res = d->res; a.res_pix_stride = d->res_pix_stride;
