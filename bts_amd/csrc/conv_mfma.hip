@@ -609,16 +609,20 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     hipError_t e;
     if (nchw) {
         auto k = conv_fwd_kernel<BM, BN, WM, WN, MF, true, PREC>;
-        if (lds > 64 * 1024) {
+        static size_t lds_allowed = 64 * 1024;               // per instantiation: raise the dynamic-LDS limit once
+        if (lds > lds_allowed) {
             e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
+            lds_allowed = lds;
         }
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, a);
     } else {
         auto k = conv_fwd_kernel<BM, BN, WM, WN, MF, false, PREC>;
-        if (lds > 64 * 1024) {
+        static size_t lds_allowed = 64 * 1024;               // per instantiation: raise the dynamic-LDS limit once
+        if (lds > lds_allowed) {
             e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
+            lds_allowed = lds;
         }
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, a);
     }
