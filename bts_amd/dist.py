@@ -62,3 +62,17 @@ def unshard_depths(gathered: torch.Tensor) -> List[torch.Tensor]:
     """[world,n_maps,b,1,H,W] -> n_maps tensors [world*b,1,H,W] in global batch order."""
     world, n_maps, b = gathered.shape[:3]
     return [gathered[:, i].reshape((world * b,) + tuple(gathered.shape[3:])) for i in range(n_maps)]
+
+
+def all_reduce_abs_min(decoder, async_op: bool = False):
+    """Global ``abs_min`` of the three LPG layers over all ranks (a 3-float all-reduce(min), only when
+    a caller wants the batch-wide diagnostic the reference logs, bts_main.py:484-486): updates
+    ``decoder.lpg{8x8,4x4,2x2}.abs_min`` in place and returns (the [3] tensor, work)."""
+    am = torch.stack([decoder.lpg8x8.abs_min, decoder.lpg4x4.abs_min, decoder.lpg2x2.abs_min]).float()
+    work = None
+    if dist.is_initialized():
+        work = dist.all_reduce(am, op=dist.ReduceOp.MIN, async_op=async_op)
+        if work is not None and not async_op:
+            work = None
+    decoder.lpg8x8.abs_min, decoder.lpg4x4.abs_min, decoder.lpg2x2.abs_min = am[0], am[1], am[2]
+    return am, work

@@ -66,6 +66,12 @@ def _worker(rank, world, port, out_dir):
             a, b = bdist.shard_range(GB, r, world)
             keep += list(range(r * bmax, r * bmax + (b - a)))
         maps = [mm[keep] for mm in maps]
+        # abs_min over all ranks: all-reduce(min) of the three per-rank LPG scalars
+        from types import SimpleNamespace
+        lp = lambda v: SimpleNamespace(abs_min=torch.tensor(float(v)))
+        fake_dec = SimpleNamespace(lpg8x8=lp(0.5 + rank), lpg4x4=lp(3.0 - rank), lpg2x2=lp(0.25))
+        am, _ = bdist.all_reduce_abs_min(fake_dec)
+        assert am.tolist() == [0.5, 3.0 - (world - 1), 0.25] and fake_dec.lpg4x4.abs_min.item() == 3.0 - (world - 1)
         if rank == 0:
             ref = run_frames(0, GB)
             for i in range(5):
