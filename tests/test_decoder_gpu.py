@@ -217,3 +217,31 @@ def test_decoder_bf16x3_mode_vs_oracle(decoders, cname):
         ops.set_conv_precision(prev)
     rep = check_outputs(got, ref_outs, inter, what=cname + " small / bf16x3")
     print(cname, "bf16x3 max-rel:", rep)
+
+
+def test_conv_bf16x3_wide_dynamic_range():
+    """The split keeps fp32's exponent range (bf16 pieces share it), so activations spanning ten decades and weights
+    spanning six lose nothing against the fp32-MFMA mode: per-OUTPUT relative error on outputs that are not
+    cancellation-dominated, both modes against fp64."""
+    import torch.nn.functional as F
+    from bts_amd import ops
+    B, cin, cout, h, w = 1, 256, 64, 12, 16
+    gen = torch.Generator().manual_seed(99)
+    x = torch.randn(B, cin, h, w, generator=gen) * torch.pow(10.0, torch.empty(B, cin, 1, 1).uniform_(-6, 4, generator=gen))
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * torch.pow(10.0, torch.empty(cout, 1, 1, 1).uniform_(-4, 2, generator=gen))
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    mag = F.conv2d(x.double().abs(), wt.double().abs(), padding=1)            # sum of |terms|: the scale rounding acts on
+    x2d = x.cuda().permute(0, 2, 3, 1).reshape(B * h * w, cin).contiguous()
+    wp, _, _ = ops.pack_conv_weight(wt.cuda())
+    worst = {}
+    for prec in ("fp32", "bf16x3"):
+        prev = ops.set_conv_precision(prec)
+        try:
+            y = torch.empty(B * h * w, cout, device="cuda")
+            ops.conv_forward(x2d, B, h, w, wp, cout, 3, y2d=y)
+        finally:
+            ops.set_conv_precision(prev)
+        got = y.view(B, h, w, cout).permute(0, 3, 1, 2).cpu().double()
+        worst[prec] = ((got - ref).abs() / mag).max().item()
+    print("error / sum|terms|:", worst)
+    assert worst["fp32"] <= 2e-6 and worst["bf16x3"] <= 2e-6, worst
