@@ -69,7 +69,7 @@ def pmc_traffic(kernel):
     except Exception:
         return None
     for k, v in tab.items():
-        mm = re.match(r"conv_fwd_kernel<(\d+),(\d+),\d+,\d+,\d+,(false|true)>", k)
+        mm = re.match(r"conv_fwd_kernel<(\d+),(\d+),\d+,\d+,\d+,(false|true)(?:,0)?>", k)   # trailing 0 = fp32-MFMA mode
         if mm and mm.group(1) == m.group(1) and mm.group(2) == m.group(2) and (mm.group(3) == "true") == (m.group(3) == "nchw"):
             return {"hbm_bytes_per_launch": int(v["hbm_MB_per_launch"] * 1e6), "source": os.path.basename(files[-1])}
     return None
