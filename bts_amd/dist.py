@@ -76,3 +76,18 @@ def all_reduce_abs_min(decoder, async_op: bool = False):
             work = None
     decoder.lpg8x8.abs_min, decoder.lpg4x4.abs_min, decoder.lpg2x2.abs_min = am[0], am[1], am[2]
     return am, work
+
+
+def shard_indices(total: int, rank: int, world: int) -> List[int]:
+    """Dataset sharding for evaluation without padding: rank r takes indices r, r+world, ... (what the reference's
+    DistributedSamplerNoEvenlyDivisible yields, distributed_sampler_no_evenly_divisible.py:62) -- ranks may differ by
+    one sample, nothing is duplicated."""
+    return list(range(rank, total, world))
+
+
+def all_reduce_eval_measures(measures: torch.Tensor) -> torch.Tensor:
+    """Sum the per-rank evaluation accumulator over all ranks (the reference's online eval keeps 9 error sums + a
+    sample count and all-reduces them, bts_main.py:258-260); returns the tensor (reduced in place)."""
+    if dist.is_initialized():
+        dist.all_reduce(measures, op=dist.ReduceOp.SUM)
+    return measures

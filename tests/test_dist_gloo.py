@@ -66,6 +66,10 @@ def _worker(rank, world, port, out_dir):
             a, b = bdist.shard_range(GB, r, world)
             keep += list(range(r * bmax, r * bmax + (b - a)))
         maps = [mm[keep] for mm in maps]
+        # online-eval accumulator (9 error sums + count, bts_main.py:258-260) and the strided eval sharding
+        acc = torch.tensor([float(rank + 1)] * 9 + [float(len(bdist.shard_indices(7, rank, world)))])
+        bdist.all_reduce_eval_measures(acc)
+        assert acc[-1].item() == 7 and acc[0].item() == sum(range(1, world + 1))
         # abs_min over all ranks: all-reduce(min) of the three per-rank LPG scalars
         from types import SimpleNamespace
         lp = lambda v: SimpleNamespace(abs_min=torch.tensor(float(v)))
@@ -80,6 +84,15 @@ def _worker(rank, world, port, out_dir):
             open(os.path.join(out_dir, "ok"), "w").write("ok")
     finally:
         dist.destroy_process_group()
+
+
+def test_shard_indices_cover_without_duplicates():
+    for total in (1, 5, 16, 697):
+        for world in (1, 2, 3, 8):
+            got = sorted(i for r in range(world) for i in bdist.shard_indices(total, r, world))
+            assert got == list(range(total))
+            sizes = [len(bdist.shard_indices(total, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
 
 
 def test_shard_range_partitions():
