@@ -320,7 +320,9 @@ def main():
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             executed = d["xflops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4),
+                    "traffic": (pmc_traffic(dom) or {}).get("hbm_bytes_per_launch"),      # HBM bytes per launch (PMC) or null
+                    "traffic_unit": "bytes/launch", "traffic_source": (pmc_traffic(dom) or {}).get("source"),
                     "executed": round(executed, 2), "executed_frac": round(executed / PEAK_MFMA_F32_TFLOPS, 4),
                     "note": "achieved = algorithmic FLOP of the reference formulation / HIP-event time of isolated full-batch "
                             "launches (the timed region overlaps %d sub-batches of the same kernels); executed = FLOP the "
