@@ -27,6 +27,7 @@ import torch.nn.functional as F
 from . import ops
 from ._lib import BtsHipError
 
+FUSED_DENSE_BLOCKS = True          # DenseNet blocks as one in-place autograd node (False: layer-by-layer graph with torch.cat)
 _WS: Dict[Tuple[str, int], torch.Tensor] = {}
 WGRAD_WS_FLOATS = 48 << 20        # 192 MB of split-K partials per (device, stream)
 
@@ -258,11 +259,11 @@ class _ConvFn(torch.autograd.Function):
                 g6 = g.view(nb, gpb, cg, k * k, gpb, cg)
                 idx = torch.arange(gpb, device=dev)
                 diag = g6[:, idx, :, :, idx, :]                         # [gpb, nb, cg_out, taps, cg_in]: each group's own block
-                dw = diag.permute(1, 0, 2, 4, 3).reshape(cout, cg, k, k)
+                dw = diag.permute(1, 0, 2, 4, 3).reshape(cout, cg, k, k).contiguous()
             else:
                 g = ops.conv_wgrad(x2d, B, h, w, c4, dy2d, co4, k, dil=dilation, stride=stride, pad=padding, up=up,
                                    ws=_workspace(dev), tag=tag + ".wgrad")
-                dw = g[:cout, :, :C].reshape(cout, k, k, C).permute(0, 3, 1, 2)
+                dw = g[:cout, :, :C].reshape(cout, k, k, C).permute(0, 3, 1, 2).contiguous()   # OIHW, the layout DDP buckets expect
         return dx, dw, None, None, None, None, None, None
 
 
@@ -412,6 +413,127 @@ def decoder_forward(dec, features, focal):
 
 
 # ------------------------------------------------------------------------------------------ encoder (DenseNet)
+class _DenseBlockFn(torch.autograd.Function):
+    """One torchvision _DenseBlock in train() mode as a single autograd node working IN PLACE on one NHWC buffer.
+
+    torchvision re-concatenates the whole prefix for every layer (and autograd then splits and re-adds the prefix
+    gradient once per layer: O(L^2) copy/add launches, 36 layers in DenseNet161's third block).  Here the block owns one
+    [B,H,W,C_total] buffer: layer i normalises the first C_i channels (a strided view), and its 3x3 convolution writes
+    its growth channels straight into columns [C_i, C_i + g).  Backward walks the layers in reverse on one gradient
+    buffer of the same shape: each layer reads its own columns as dy and adds its input gradient onto the prefix.
+    Saved per layer: the 1x1 output and the four BN vectors of both norms; the normalised inputs are recomputed
+    (one elementwise pass) instead of stored."""
+
+    @staticmethod
+    def forward(ctx, x, block, *params):
+        B, C0, H, W = x.shape
+        layers = list(block.values())
+        g = layers[0].conv2.out_channels
+        mid = layers[0].conv1.out_channels
+        Ct = C0 + len(layers) * g
+        npix = B * H * W
+        dev = x.device
+        buf = torch.empty((npix, Ct), dtype=torch.float32, device=dev)
+        buf[:, :C0] = x.detach().permute(0, 2, 3, 1).reshape(npix, C0)
+        a1 = torch.empty((npix, Ct), dtype=torch.float32, device=dev)       # scratch: normalised prefix of the current layer
+        a2 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
+        saved = []
+        ws = _bn_workspace(dev, ops.bn_train_ws_floats(npix, Ct))
+        sk = _splitk_workspace(dev)
+        for i, L in enumerate(layers):
+            Ci = C0 + i * g
+            s1 = ops.bn_train_stats(buf[:, :Ci], Ci, L.norm1.weight.detach(), L.norm1.bias.detach(), L.norm1.eps,
+                                    L.norm1.momentum, L.norm1.running_mean, L.norm1.running_var, ws)
+            ops.bn_apply(buf[:, :Ci], Ci, s1[2], s1[3], True, a1[:, :Ci])
+            t1 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
+            ops.conv_forward(a1[:, :Ci], B, H, W, _PACKER.get(L.conv1.weight, Ci, WeightPacker.FWD), mid, 1, c_in_ld=Ci,
+                             y2d=t1, tag="enc.fwd", splitk_ws=sk)
+            s2 = ops.bn_train_stats(t1, mid, L.norm2.weight.detach(), L.norm2.bias.detach(), L.norm2.eps,
+                                    L.norm2.momentum, L.norm2.running_mean, L.norm2.running_var, ws)
+            ops.bn_apply(t1, mid, s2[2], s2[3], True, a2)
+            ops.conv_forward(a2, B, H, W, _PACKER.get(L.conv2.weight, mid, WeightPacker.FWD), g, 3, c_in_ld=mid,
+                             y2d=buf[:, Ci:Ci + g], tag="enc.fwd", splitk_ws=sk)
+            for bn in (L.norm1, L.norm2):
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+            saved += [t1, torch.stack(s1), torch.stack(s2)]
+        ctx.save_for_backward(buf, *saved)
+        ctx.block = block
+        ctx.geom = (B, C0, H, W, g, mid, Ct)
+        return buf.view(B, H, W, Ct).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        buf, *saved = ctx.saved_tensors
+        B, C0, H, W, g, mid, Ct = ctx.geom
+        layers = list(ctx.block.values())
+        npix = B * H * W
+        dev = grad_out.device
+        G = grad_out.permute(0, 2, 3, 1).reshape(npix, Ct).contiguous().clone()
+        a1 = torch.empty((npix, Ct), dtype=torch.float32, device=dev)
+        a2 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
+        d_a2 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
+        d_t1 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
+        d_a1 = torch.empty((npix, Ct), dtype=torch.float32, device=dev)
+        dpre = torch.empty((npix, Ct), dtype=torch.float32, device=dev)
+        ws = _bn_workspace(dev, ops.bn_train_ws_floats(npix, Ct))
+        wws = _workspace(dev)
+        sk = _splitk_workspace(dev)
+        grads = [None] * (6 * len(layers))
+        need = ctx.needs_input_grad
+        for i in range(len(layers) - 1, -1, -1):
+            L = layers[i]
+            Ci = C0 + i * g
+            t1, s1, s2 = saved[3 * i], saved[3 * i + 1], saved[3 * i + 2]
+            gy = G[:, Ci:Ci + g]                                               # this layer's output gradient, in place
+            ops.bn_apply(t1, mid, s2[2], s2[3], True, a2)                      # recompute relu(norm2(t1))
+            ops.conv_forward(gy, B, H, W, _PACKER.get(L.conv2.weight, g, WeightPacker.DGRAD), mid, 3, c_in_ld=g, y2d=d_a2,
+                             pad=1, tag="enc.dgrad", splitk_ws=sk)
+            if need[2 + 6 * i + 5]:
+                w2 = ops.conv_wgrad(a2, B, H, W, mid, gy, g, 3, ws=wws, tag="enc.wgrad")
+                grads[6 * i + 5] = w2.reshape(g, 3, 3, mid).permute(0, 3, 1, 2).contiguous()
+            dg2, db2 = ops.bn_train_backward(t1, d_a2, mid, s2[0], s2[1], s2[2], s2[3], True, ws, d_t1)
+            if need[2 + 6 * i + 3]:
+                grads[6 * i + 3] = dg2
+            if need[2 + 6 * i + 4]:
+                grads[6 * i + 4] = db2
+            ops.bn_apply(buf[:, :Ci], Ci, s1[2], s1[3], True, a1[:, :Ci])      # recompute relu(norm1(prefix))
+            ops.conv_forward(d_t1, B, H, W, _PACKER.get(L.conv1.weight, mid, WeightPacker.DGRAD), Ci, 1, c_in_ld=mid,
+                             y2d=d_a1[:, :Ci], pad=0, tag="enc.dgrad", splitk_ws=sk)
+            if need[2 + 6 * i + 2]:
+                w1 = ops.conv_wgrad(a1[:, :Ci], B, H, W, Ci, d_t1, mid, 1, ws=wws, tag="enc.wgrad")
+                grads[6 * i + 2] = w1.reshape(mid, Ci, 1, 1)
+            dg1, db1 = ops.bn_train_backward(buf[:, :Ci], d_a1[:, :Ci], Ci, s1[0], s1[1], s1[2], s1[3], True, ws, dpre[:, :Ci])
+            if need[2 + 6 * i + 0]:
+                grads[6 * i + 0] = dg1
+            if need[2 + 6 * i + 1]:
+                grads[6 * i + 1] = db1
+            G[:, :Ci] += dpre[:, :Ci]                                          # the prefix receives this layer's input gradient
+        dx = G[:, :C0].reshape(B, H, W, C0).permute(0, 3, 1, 2) if need[0] else None
+        return (dx, None) + tuple(grads)
+
+
+def _dense_block(block, x):
+    """Fused in-place dense block when every norm layer is an ordinary train()-mode BatchNorm2d with affine parameters
+    and channel counts the kernels take (multiples of 4); otherwise the generic layer-by-layer graph."""
+    nn = torch.nn
+    layers = list(block.values())
+    ok = x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0
+    for L in layers:
+        for bn in (L.norm1, L.norm2):
+            ok = ok and isinstance(bn, nn.BatchNorm2d) and bn.training and bn.momentum is not None and bn.affine \
+                and bn.track_running_stats and bn.running_mean is not None
+        ok = ok and L.conv1.bias is None and L.conv2.bias is None and L.conv2.out_channels % 4 == 0 \
+            and L.conv1.out_channels % 4 == 0 and L.conv2.padding[0] == 1 and L.conv1.kernel_size[0] == 1 \
+            and L.conv2.kernel_size[0] == 3
+    if not ok:
+        return None
+    params = []
+    for L in layers:
+        params += [L.norm1.weight, L.norm1.bias, L.conv1.weight, L.norm2.weight, L.norm2.bias, L.conv2.weight]
+    return _DenseBlockFn.apply(x, block, *params)
+
+
 def _run_children(children, x, tapped=None, taps=None):
     """Run (name, module) pairs in order on the HIP kernels: bias-free ungrouped convolutions, batch-statistic BN
     with the ReLU that follows it fused in; pools and stray activations are the modules themselves.
@@ -433,7 +555,9 @@ def _run_children(children, x, tapped=None, taps=None):
             if fuse:
                 i += 1
                 last = children[i][0]
-        elif isinstance(child, nn.ModuleDict):               # _DenseBlock: each layer sees the concat of all earlier ones
+        elif isinstance(child, nn.ModuleDict) and FUSED_DENSE_BLOCKS and (fused := _dense_block(child, x)) is not None:
+            x = fused                                        # one autograd node, one NHWC buffer, no torch.cat
+        elif isinstance(child, nn.ModuleDict):               # _DenseBlock, generic graph: each layer sees the concat of all earlier ones
             feats = [x]
             for layer in child.values():
                 y = torch.cat(feats, 1) if len(feats) > 1 else feats[0]
