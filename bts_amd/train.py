@@ -435,8 +435,6 @@ class _DenseBlockFn(torch.autograd.Function):
         dev = x.device
         buf = torch.empty((npix, Ct), dtype=torch.float32, device=dev)
         buf[:, :C0] = x.detach().permute(0, 2, 3, 1).reshape(npix, C0)
-        a1 = torch.empty((npix, Ct), dtype=torch.float32, device=dev)       # scratch: normalised prefix of the current layer
-        a2 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
         saved = []
         ws = _bn_workspace(dev, ops.bn_train_ws_floats(npix, Ct))
         sk = _splitk_workspace(dev)
@@ -444,15 +442,15 @@ class _DenseBlockFn(torch.autograd.Function):
             Ci = C0 + i * g
             s1 = ops.bn_train_stats(buf[:, :Ci], Ci, L.norm1.weight.detach(), L.norm1.bias.detach(), L.norm1.eps,
                                     L.norm1.momentum, L.norm1.running_mean, L.norm1.running_var, ws)
-            ops.bn_apply(buf[:, :Ci], Ci, s1[2], s1[3], True, a1[:, :Ci])
+            # norm + ReLU ride in the convolutions' prologue (applied on the way to LDS): the normalised tensors are
+            # never written in the forward pass
             t1 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
-            ops.conv_forward(a1[:, :Ci], B, H, W, _PACKER.get(L.conv1.weight, Ci, WeightPacker.FWD), mid, 1, c_in_ld=Ci,
-                             y2d=t1, tag="enc.fwd", splitk_ws=sk)
+            ops.conv_forward(buf[:, :Ci], B, H, W, _PACKER.get(L.conv1.weight, Ci, WeightPacker.FWD), mid, 1, c_in_ld=Ci,
+                             pre=(s1[2], s1[3]), pre_relu=True, y2d=t1, tag="enc.fwd", splitk_ws=sk)
             s2 = ops.bn_train_stats(t1, mid, L.norm2.weight.detach(), L.norm2.bias.detach(), L.norm2.eps,
                                     L.norm2.momentum, L.norm2.running_mean, L.norm2.running_var, ws)
-            ops.bn_apply(t1, mid, s2[2], s2[3], True, a2)
-            ops.conv_forward(a2, B, H, W, _PACKER.get(L.conv2.weight, mid, WeightPacker.FWD), g, 3, c_in_ld=mid,
-                             y2d=buf[:, Ci:Ci + g], tag="enc.fwd", splitk_ws=sk)
+            ops.conv_forward(t1, B, H, W, _PACKER.get(L.conv2.weight, mid, WeightPacker.FWD), g, 3, c_in_ld=mid,
+                             pre=(s2[2], s2[3]), pre_relu=True, y2d=buf[:, Ci:Ci + g], tag="enc.fwd", splitk_ws=sk)
             for bn in (L.norm1, L.norm2):
                 if bn.num_batches_tracked is not None:
                     bn.num_batches_tracked.add_(1)
