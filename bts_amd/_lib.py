@@ -19,7 +19,7 @@ SYMBOLS = (
     "bts_pack_weights_blocks", "bts_pack_weights_f32",
 )
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvDesc(C.Structure):
@@ -47,6 +47,7 @@ class ConvWgradDesc(C.Structure):
         ("B", C.c_int), ("h_in", C.c_int), ("w_in", C.c_int),
         ("up", C.c_int), ("ksize", C.c_int), ("dil", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
         ("dw", C.c_void_p), ("ws", C.c_void_p), ("ws_floats", C.c_long), ("n_bundles", C.c_int),
+        ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("pre_relu", C.c_int),
     ]
 
 

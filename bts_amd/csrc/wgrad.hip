@@ -28,6 +28,8 @@ struct WgradArgs {
     unsigned M;                  // B*H*W output pixels
     unsigned pix_per_split;      // multiple of WBK
     int n_ntiles;
+    const float* pre_scale; const float* pre_shift; int pre_relu;   // optional per-input-channel affine (+ReLU) applied to x
+                                 // in the gather: the forward convolution saw relu(x*scale + shift) (a folded norm layer)
     int n_bundles;               // grouped convolution as channel bundles (blockIdx.z): bundle j uses input channels
                                  // [j*c_in, ..), gradient channels [j*c_out, ..) and writes dense block j of [c_out][N]
 };
@@ -75,6 +77,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     // Two staging register sets: the loads of tile it+2 are issued at the top of step it and consumed (written to LDS)
     // at the bottom of step it+1, so every global load has two full MFMA steps to land.
     f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+    f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};          // this thread's four input channels never change
+    const bool has_pre = a.pre_scale != nullptr;
+    if (has_pre) {
+        const int cpre = blockIdx.z * a.c_in + ci;
+        psc = *reinterpret_cast<const f32x4*>(a.pre_scale + cpre);
+        psh = *reinterpret_cast<const f32x4*>(a.pre_shift + cpre);
+    }
     int pb[PB], py[PB], px[PB];             // (frame, row, column) of each gathered row's output pixel at the next step
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
@@ -102,7 +111,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
             const int sb = ok ? pb[p] : 0, sy = ok ? (iy >> a.ups) : 0, sx = ok ? (ix >> a.ups) : 0;
             const float* src = xg + ((size_t)(sb * a.h_in + sy) * a.w_in + sx) * a.x_pix_stride + ci;
             f32x4 v = *reinterpret_cast<const f32x4*>(src);
-            rb[p] = ok ? v : (f32x4)(0.f);
+            if (has_pre) {
+                v = v * psc + psh;
+                if (a.pre_relu) v = __builtin_elementwise_max(v, (f32x4)(0.f));
+            }
+            rb[p] = ok ? v : (f32x4)(0.f);                               // zero padding AFTER the prologue
             // advance this row's output pixel by one K-step without dividing (issue() is called for it = 0, 1, 2, ...)
             px[p] += WBK;
             while (px[p] >= a.W) { px[p] -= a.W; ++py[p]; }
@@ -300,6 +313,8 @@ extern "C" int bts_conv_wgrad_f32(const bts_conv_wgrad_desc* d, bts_stream_t str
     a.N = d->ksize * d->ksize * d->c_in;
     a.pix_per_split = 0; a.n_ntiles = 0;
     hipStream_t s = (hipStream_t)stream;
+    a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift; a.pre_relu = d->pre_relu;
+    if (d->pre_scale && (!d->pre_shift || ((uintptr_t)d->pre_scale & 15) || ((uintptr_t)d->pre_shift & 15))) return BTS_ERR_INVALID;
     a.n_bundles = d->n_bundles > 1 ? d->n_bundles : 1;
     if (d->n_bundles < 0 || a.n_bundles > 65535) return BTS_ERR_INVALID;
     if (d->x_pix_stride < (long)a.n_bundles * d->c_in || d->dy_pix_stride < (long)a.n_bundles * d->c_out) return BTS_ERR_INVALID;

@@ -480,7 +480,8 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
 
 def conv_wgrad(x2d: torch.Tensor, B: int, h_in: int, w_in: int, c_in: int, dy2d: torch.Tensor, c_out: int,
                ksize: int, dil: int = 1, stride: int = 1, pad: Optional[int] = None, up: int = 1,
-               ws: Optional[torch.Tensor] = None, tag: str = "wgrad", n_bundles: int = 1) -> torch.Tensor:
+               ws: Optional[torch.Tensor] = None, tag: str = "wgrad", n_bundles: int = 1,
+               pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_relu: bool = False) -> torch.Tensor:
     """Weight gradient of one bias-free convolution (bts_conv_wgrad_f32): returns dw as [c_out, ksize*ksize, c_in]
     (OHWI).  x2d: [B*h_in*w_in, >=c_in] NHWC view of the forward input, dy2d: [B*H*W, >=c_out] NHWC view of the
     output gradient; c_in and c_out multiples of 4 (pad with zero channels).  ``n_bundles`` > 1: grouped convolution
@@ -500,6 +501,10 @@ def conv_wgrad(x2d: torch.Tensor, B: int, h_in: int, w_in: int, c_in: int, dy2d:
     dw = torch.empty(shape, dtype=torch.float32, device=x2d.device)
     d = ConvWgradDesc()
     d.n_bundles = n_bundles if n_bundles > 1 else 0
+    if pre is not None:                       # the forward conv saw [relu](x*scale + shift): gather the same thing
+        if pre[0].numel() != c_in * max(n_bundles, 1) or pre[1].numel() != pre[0].numel():
+            raise BtsHipError("conv_wgrad: pre vectors must have c_in entries")
+        d.pre_scale, d.pre_shift, d.pre_relu = pre[0].data_ptr(), pre[1].data_ptr(), int(bool(pre_relu))
     d.x, d.x_pix_stride, d.c_in = x2d.data_ptr(), xs, c_in
     d.dy, d.dy_pix_stride, d.c_out = dy2d.data_ptr(), ds, c_out
     d.B, d.h_in, d.w_in, d.up, d.ksize, d.dil, d.stride, d.pad = B, h_in, w_in, up, ksize, dil, stride, pad

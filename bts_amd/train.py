@@ -421,8 +421,8 @@ class _DenseBlockFn(torch.autograd.Function):
     [B,H,W,C_total] buffer: layer i normalises the first C_i channels (a strided view), and its 3x3 convolution writes
     its growth channels straight into columns [C_i, C_i + g).  Backward walks the layers in reverse on one gradient
     buffer of the same shape: each layer reads its own columns as dy and adds its input gradient onto the prefix.
-    Saved per layer: the 1x1 output and the four BN vectors of both norms; the normalised inputs are recomputed
-    (one elementwise pass) instead of stored."""
+    Saved per layer: the 1x1 output and the four BN vectors of both norms; the normalised inputs are never materialised --
+    norm + ReLU ride in the prologue of the forward convolutions and of the weight-gradient gather."""
 
     @staticmethod
     def forward(ctx, x, block, *params):
@@ -468,8 +468,6 @@ class _DenseBlockFn(torch.autograd.Function):
         npix = B * H * W
         dev = grad_out.device
         G = grad_out.permute(0, 2, 3, 1).reshape(npix, Ct).contiguous().clone()
-        a1 = torch.empty((npix, Ct), dtype=torch.float32, device=dev)
-        a2 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
         d_a2 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
         d_t1 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
         d_a1 = torch.empty((npix, Ct), dtype=torch.float32, device=dev)
@@ -484,22 +482,21 @@ class _DenseBlockFn(torch.autograd.Function):
             Ci = C0 + i * g
             t1, s1, s2 = saved[3 * i], saved[3 * i + 1], saved[3 * i + 2]
             gy = G[:, Ci:Ci + g]                                               # this layer's output gradient, in place
-            ops.bn_apply(t1, mid, s2[2], s2[3], True, a2)                      # recompute relu(norm2(t1))
             ops.conv_forward(gy, B, H, W, _PACKER.get(L.conv2.weight, g, WeightPacker.DGRAD), mid, 3, c_in_ld=g, y2d=d_a2,
                              pad=1, tag="enc.dgrad", splitk_ws=sk)
-            if need[2 + 6 * i + 5]:
-                w2 = ops.conv_wgrad(a2, B, H, W, mid, gy, g, 3, ws=wws, tag="enc.wgrad")
+            if need[2 + 6 * i + 5]:                # the weight-gradient gather re-applies norm2 + ReLU to t1 on the fly
+                w2 = ops.conv_wgrad(t1, B, H, W, mid, gy, g, 3, ws=wws, tag="enc.wgrad", pre=(s2[2], s2[3]), pre_relu=True)
                 grads[6 * i + 5] = w2.reshape(g, 3, 3, mid).permute(0, 3, 1, 2).contiguous()
             dg2, db2 = ops.bn_train_backward(t1, d_a2, mid, s2[0], s2[1], s2[2], s2[3], True, ws, d_t1)
             if need[2 + 6 * i + 3]:
                 grads[6 * i + 3] = dg2
             if need[2 + 6 * i + 4]:
                 grads[6 * i + 4] = db2
-            ops.bn_apply(buf[:, :Ci], Ci, s1[2], s1[3], True, a1[:, :Ci])      # recompute relu(norm1(prefix))
             ops.conv_forward(d_t1, B, H, W, _PACKER.get(L.conv1.weight, mid, WeightPacker.DGRAD), Ci, 1, c_in_ld=mid,
                              y2d=d_a1[:, :Ci], pad=0, tag="enc.dgrad", splitk_ws=sk)
             if need[2 + 6 * i + 2]:
-                w1 = ops.conv_wgrad(a1[:, :Ci], B, H, W, Ci, d_t1, mid, 1, ws=wws, tag="enc.wgrad")
+                w1 = ops.conv_wgrad(buf[:, :Ci], B, H, W, Ci, d_t1, mid, 1, ws=wws, tag="enc.wgrad", pre=(s1[2], s1[3]),
+                                    pre_relu=True)
                 grads[6 * i + 2] = w1.reshape(mid, Ci, 1, 1)
             dg1, db1 = ops.bn_train_backward(buf[:, :Ci], d_a1[:, :Ci], Ci, s1[0], s1[1], s1[2], s1[3], True, ws, dpre[:, :Ci])
             if need[2 + 6 * i + 0]:

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 3
+#define BTS_HIP_ABI_VERSION 4
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -190,6 +190,9 @@ typedef struct bts_conv_wgrad_desc {
                                c_in / c_out are PER BUNDLE, bundle j uses x channels [j*c_in, ..) and dy channels
                                [j*c_out, ..); dw = [n_bundles][c_out][ksize*ksize][c_in] dense blocks, of which the
                                caller keeps each group's diagonal block                                            */
+    const float* pre_scale; /* optional [n_bundles*c_in] (16-byte aligned): the forward convolution consumed           */
+    const float* pre_shift; /* relu?(x*pre_scale + pre_shift) (a norm layer folded into its prologue, see               */
+    int   pre_relu;         /* bts_conv_desc.pre_*); the gather applies the same transform, padding stays zero        */
 } bts_conv_wgrad_desc;
 
 int bts_conv_wgrad_f32(const bts_conv_wgrad_desc* desc, bts_stream_t stream);

@@ -102,6 +102,26 @@ def test_grouped_and_strided_conv_gradients_vs_torch_cpu(case):
         assert err <= 5e-5 * scale, (what, err, scale)
 
 
+def test_wgrad_input_prologue_matches_materialised_input():
+    """bts_conv_wgrad_desc.pre_*: gathering relu(x*scale + shift) on the fly == the weight gradient on the materialised
+    tensor (zero padding stays zero: a shift must not leak into the border taps)."""
+    from bts_amd import ops
+    B, h, w, cin, cout = 2, 9, 13, 64, 32
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(B * h * w, cin, generator=gen).cuda()
+    dy = torch.randn(B * h * w, cout, generator=gen).cuda()
+    sc = (torch.rand(cin, generator=gen) + 0.5).cuda()
+    sh = (torch.randn(cin, generator=gen) * 0.5 + 0.3).cuda()
+    ws = torch.empty(4 << 20, device="cuda")
+    mat = torch.relu(x * sc + sh)
+    ref = ops.conv_wgrad(mat, B, h, w, cin, dy, cout, 3, ws=ws)
+    got = ops.conv_wgrad(x, B, h, w, cin, dy, cout, 3, ws=ws, pre=(sc, sh), pre_relu=True)
+    assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    ref1 = ops.conv_wgrad(x * sc + sh, B, h, w, cin, dy, cout, 1, ws=ws)
+    got1 = ops.conv_wgrad(x, B, h, w, cin, dy, cout, 1, ws=ws, pre=(sc, sh), pre_relu=False)
+    assert (got1 - ref1).abs().max().item() <= 1e-5 * ref1.abs().max().item()
+
+
 def test_wgrad_split_is_deterministic_and_matches_unsplit():
     """The pixel split only regroups a sum: with and without workspace agree to fp32 rounding, and two runs of the
     split path are bit-identical (fixed-order reduction, no atomics)."""
