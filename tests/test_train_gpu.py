@@ -477,3 +477,30 @@ def test_fused_dense_block_equals_layer_by_layer_graph():
     print("fused vs layer-by-layer: global rel-L2 %.2e, worst tensor %.2e" % (l2, max(per.values())))
     # same kernels, same inputs, only the association of a few sums differs: measured 4.7e-7 global, 5.5e-6 worst
     assert_grads_close(per, l2, "fused dense block vs generic graph", typical=1e-4, worst=2e-3, l2=1e-4)
+
+
+def test_training_graph_with_frozen_batchnorm_layers():
+    """bts_main.py --bn_no_track_stats applies bn_init_as_tf (norm layers in eval mode inside a train()-mode model):
+    the graph then normalises with the running statistics, leaves the buffers untouched, and still back-propagates."""
+    from bts_amd import bts as M, trainer
+    params = Params("densenet121_bts", 512, 80.0, "kitti")
+    torch.manual_seed(5)
+    model = M.BtsModel(params).train().cuda()
+    trainer.set_misc(model, params.encoder, bn_no_track_stats=True)
+    assert not model.decoder.bn5.training and model.decoder.conv5.training
+    before = {n: b.clone() for n, b in model.named_buffers() if "running" in n}
+    B, H, W = 1, 64, 96
+    x = torch.from_numpy(synth.image_batch(B, H, W, 2)).cuda()
+    focal = torch.from_numpy(synth.focal_values(B, "kitti", 2)).cuda()
+    gt, mask = synth.train_targets(B, H, W, 80.0, 2)
+    outs = model(x, focal)
+    loss = M.silog_loss(0.85)(outs[4], t(gt).cuda(), t(mask).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.isfinite(loss.item())
+    for n, b in model.named_buffers():
+        if "running" in n:
+            assert torch.equal(b, before[n]), n
+    g = model.decoder.conv5[0].weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0
+    assert model.encoder.base_model.denseblock2.denselayer3.conv2.weight.grad is not None
