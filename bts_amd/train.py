@@ -550,14 +550,16 @@ def _run_children(children, x, tapped=None, taps=None):
             if fuse:
                 i += 1
                 last = children[i][0]
-        elif isinstance(child, nn.ModuleDict) and FUSED_DENSE_BLOCKS and (fused := _dense_block(child, x)) is not None:
-            x = fused                                        # one autograd node, one NHWC buffer, no torch.cat
-        elif isinstance(child, nn.ModuleDict):               # _DenseBlock, generic graph: each layer sees the concat of all earlier ones
-            feats = [x]
-            for layer in child.values():
-                y = torch.cat(feats, 1) if len(feats) > 1 else feats[0]
-                feats.append(_run_children(list(layer.named_children()), y))   # norm1 relu1 conv1 norm2 relu2 conv2
-            x = torch.cat(feats, 1)
+        elif isinstance(child, nn.ModuleDict):               # _DenseBlock
+            fused = _dense_block(child, x) if FUSED_DENSE_BLOCKS else None
+            if fused is not None:
+                x = fused                                    # one autograd node, one NHWC buffer, no torch.cat
+            else:                                            # generic graph: each layer sees the concat of all earlier ones
+                feats = [x]
+                for layer in child.values():
+                    y = torch.cat(feats, 1) if len(feats) > 1 else feats[0]
+                    feats.append(_run_children(list(layer.named_children()), y))   # norm1 relu1 conv1 norm2 relu2 conv2
+                x = torch.cat(feats, 1)
         elif isinstance(child, nn.Sequential):               # _Transition
             x = _run_children(list(child.named_children()), x)
         else:
