@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark: depth frames/s of BtsModel.forward (DenseNet161 encoder on PyTorch-ROCm + the
-all-HIP decoder hot path) at B=16 per GPU, 3x352x1216 fp32 synthetic KITTI-shape input
-(BASELINE.json configs[1]); weak scaling over N GPUs (one process per GPU, RCCL).
+"""Headline benchmark: depth frames/s of BtsModel.forward -- the DenseNet161 encoder AND the decoder hot path both on
+the hand-written HIP kernels of libbts_hip.so -- at B=16 per GPU, 3x352x1216 fp32 synthetic KITTI-shape input
+(BASELINE.json configs[1]); one process per GPU, RCCL.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...                    # starts the N ranks itself (the reference: mp.spawn, bts_main.py:843-847)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W       # or under torchrun: RANK / LOCAL_RANK / WORLD_SIZE from the env
+    python bench.py --gpus 8 --global-batch 64      # BASELINE.json configs[3]: B=64 sharded 8 x 8 (strong scaling)
 
+Weak scaling by default (--batch frames per GPU); --global-batch G fixes the total and shards it.  `n_gpus` in the
+JSON line is the number of ranks RCCL actually formed; a mismatch with --gpus is an error, never a silent 1-GPU run.
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant hand-written
 kernel, HIP-event timed on its launch stream) and `cpu_baseline` (the CPU oracle on the host cores).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from collections import namedtuple
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # encoder convs (MIOpen): no exhaustive search on a fresh box
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # only read by --encoder-backend miopen (A/B leg; MIOpen is off otherwise)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
@@ -56,10 +62,13 @@ def build_model(params, device, seed=0):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json:
-    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command); None if absent.
-    Counters cannot be collected from inside the benchmark process itself."""
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command).  Counters cannot be
+    collected from inside the benchmark process itself, so the file carries the hash of the kernel sources it was
+    measured on (`_meta.csrc_sha16`, scripts/pmc_traffic.py); a file measured on OTHER kernel sources yields
+    traffic = null (stale) instead of a wrong number."""
     import glob
     import re
+    from bts_amd import _lib
     m = re.match(r"conv_fwd_kernel<(\d+),(\d+),(nhwc|nchw)>", kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not m or not files:
@@ -68,10 +77,18 @@ def pmc_traffic(kernel):
         tab = json.load(open(files[-1]))
     except Exception:
         return None
+    meta = tab.get("_meta", {})
+    src = {"source": os.path.basename(files[-1]), "profile_csrc_sha16": meta.get("csrc_sha16"),
+           "profile_commit": meta.get("commit"), "current_csrc_sha16": _lib.source_hash()}
+    if meta.get("csrc_sha16") != src["current_csrc_sha16"]:
+        src["hbm_bytes_per_launch"] = None
+        src["stale"] = True
+        return src
     for k, v in tab.items():
         mm = re.match(r"conv_fwd_kernel<(\d+),(\d+),\d+,\d+,\d+,(false|true)(?:,0)?>", k)   # trailing 0 = fp32-MFMA mode
         if mm and mm.group(1) == m.group(1) and mm.group(2) == m.group(2) and (mm.group(3) == "true") == (m.group(3) == "nchw"):
-            return {"hbm_bytes_per_launch": int(v["hbm_MB_per_launch"] * 1e6), "source": os.path.basename(files[-1])}
+            src["hbm_bytes_per_launch"] = int(v["hbm_MB_per_launch"] * 1e6)
+            return src
     return None
 
 
@@ -152,26 +169,37 @@ def cpu_baseline(params, H, W, seconds_budget=15.0, gpu_frame0=None, extra_frame
     return out, parity, extra_parity
 
 
-def baseline_config_label(enc, B, H, W):
+def baseline_config_label(enc, b, G, world, scaling, H, W):
     """Which BASELINE.json configuration a run corresponds to (the metric is quoted on configs[1])."""
-    if (enc, B, H, W) == ("densenet161_bts", 16, 352, 1216):
-        return " (BASELINE.json configs[1])"
-    if (enc, B, H, W) == ("resnext101_bts", 16, 416, 544):
+    if (enc, b, H, W, scaling) == ("densenet161_bts", 16, 352, 1216, "weak"):
+        return " (BASELINE.json configs[1]%s)" % ("" if world == 1 else ", weak-scaled to %d GPUs" % world)
+    if (enc, G, H, W, scaling) == ("densenet161_bts", 64, 352, 1216, "strong"):
+        return " (BASELINE.json configs[3]: B=64 batch-sharded%s)" % (
+            " over 8 GPUs" if world == 8 else "; run here on %d GPU%s of the 8 it names" % (world, "" if world == 1 else "s"))
+    if (enc, b, H, W) == ("resnext101_bts", 16, 416, 544):
         return " (BASELINE.json configs[2], not the headline configuration)"
     return " (not a BASELINE.json configuration)"
 
 
-def main():
-    # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL does at init) are
-    # sent to stderr for the whole run; the JSON goes to the saved descriptor at the end
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="number of ranks (one process per GPU).  Outside torchrun, N > 1 makes this process start the N "
+                         "ranks itself; under torchrun it must equal WORLD_SIZE")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: total frames, sharded contiguously over the ranks (64 over 8 GPUs = BASELINE.json "
+                         "configs[3]); must be a multiple of --gpus.  0 = weak scaling with --batch per GPU")
     ap.add_argument("--height", type=int, default=352)
     ap.add_argument("--width", type=int, default=1216)
     ap.add_argument("--encoder", default="densenet161_bts")
@@ -190,19 +218,148 @@ def main():
                     help="hip: DenseNet encoder on the HIP conv kernel (default); aten: torch encoder on ATen's native "
                          "conv path; miopen: torch encoder on MIOpen (no gfx950 find-db in this image: the first pass "
                          "JIT-compiles ~160 conv configs for >7 min)")
-    args = ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port for the self-started ranks (0 = pick a free one)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="exercise ONLY the multi-rank plumbing on CPU (gloo): launcher, rendezvous, shard plan, barrier + "
+                         "max-over-ranks timing, the packed all-gather.  No hot-path compute, no frames/s value")
+    return ap
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this very script, one per GPU (the reference
+    starts its workers the same way: mp.spawn(main_worker, nprocs=ngpus), bts_main.py:843-847, and rendezvous over
+    tcp://127.0.0.1, bts_main.py:295).  The parent never initialises the GPU (torch.cuda.device_count() does not, on
+    this image); it waits for the ranks, relays rank 0's JSON line and exits with the first failing rank's code."""
+    n = args.gpus
+    if not args.launcher_selftest:
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench.py: --gpus %d requested but only %d GPU%s visible on this node; refusing to run fewer ranks than "
+                  "asked for (the JSON line's n_gpus must be the number of ranks that really ran)" % (n, have, "" if have == 1 else "s"),
+                  file=sys.stderr)
+            return 2
+    port = args.master_port or _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc = 0
+    out0 = b""
+    try:
+        # rank 0's stdout is one JSON line: read it to EOF, then reap everyone; a rank that dies takes the others with it
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        print("bench.py: rank %d exited with code %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                        for q in pending:
+                            procs[q].terminate()
+            if 0 in pending:
+                try:
+                    out0 += procs[0].stdout.read1(65536) if hasattr(procs[0].stdout, "read1") else b""
+                except Exception:
+                    pass
+            time.sleep(0.05)
+        out0 += procs[0].stdout.read() or b""
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    if rc == 0:
+        sys.stdout.write(out0.decode())
+        sys.stdout.flush()
+    return rc
+
+
+def shard_plan(args, world):
+    """(frames per rank, global batch, scaling label).  Weak: --batch per GPU.  Strong: --global-batch split into equal
+    contiguous blocks (DataParallel.scatter order, bts_test.py:91)."""
+    if args.global_batch > 0:
+        if args.global_batch % world:
+            raise SystemExit("bench.py: --global-batch %d is not a multiple of %d ranks" % (args.global_batch, world))
+        return args.global_batch // world, args.global_batch, "strong"
+    return args.batch, args.batch * world, "weak"
+
+
+def launcher_selftest(args, world, rank):
+    """CPU / gloo stand-in for the N-rank run: everything around the hot path that bench.py does for N > 1."""
+    from bts_amd import dist as bdist
+    dist.init_process_group(backend="gloo")
+    formed = dist.get_world_size()
+    b, G, scaling = shard_plan(args, formed)
+    lo, hi = bdist.shard_range(G, rank, formed)
+    assert hi - lo == b, "equal contiguous shards"
+    m = torch.nn.Linear(4, 3)
+    with torch.no_grad():
+        m.weight.fill_(float(rank + 1))
+    bdist.broadcast_module(m, src=0)
+    assert float(m.weight.detach()[0, 0]) == 1.0, "weights come from rank 0"
+    outs = [torch.full((b, 1, 2, 3), float(10 * rank + i)) for i in range(6)]
+    dist.barrier()
+    t0 = time.perf_counter()
+    gathered, work = bdist.all_gather_depths(outs, 5, async_op=True)
+    work.wait()
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0 + 0.001 * rank], dtype=torch.float64)
+    mine = float(tt.item())
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    maps = bdist.unshard_depths(gathered)
+    ok = all(float(maps[i][r * b, 0, 0, 0]) == 10 * r + i for i in range(5) for r in range(formed))
+    line = {"selftest": "launcher", "n_gpus": formed, "requested_gpus": args.gpus, "scaling": scaling,
+            "global_batch": G, "batch_per_gpu": b, "shard": [lo, hi], "gather_ok": bool(ok),
+            "elapsed_is_max_over_ranks": bool(float(tt.item()) >= mine), "value": None, "backend": "gloo"}
+    dist.barrier()
+    dist.destroy_process_group()
+    return line
+
+
+def main():
+    # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL does at init) are
+    # sent to stderr for the whole run; the JSON goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    args = build_parser().parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torchrun: this process only starts the ranks (it must not touch the GPU) and relays rank 0's line
+        os.dup2(real_stdout, 1)
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher environment says WORLD_SIZE=%d; refusing to report a run whose "
+              "n_gpus differs from what was asked for" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if args.launcher_selftest:
+        line = launcher_selftest(args, world, rank)
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        return
     use_dist = world > 1 or bool(os.environ.get("BTS_BENCH_FORCE_DIST"))   # FORCE: exercise RCCL with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        if torch.cuda.device_count() <= local_rank:
+            print("bench.py: rank %d has no GPU %d on this node (%d visible)" % (rank, local_rank, torch.cuda.device_count()),
+                  file=sys.stderr)
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            print("bench.py: RCCL formed %d ranks, --gpus asked for %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
+            sys.exit(2)
+        world = dist.get_world_size()          # n_gpus in the JSON line = the ranks RCCL actually formed
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
@@ -212,7 +369,8 @@ def main():
     from bts_amd import dist as bdist, ops, synth
     is_kitti = args.dataset == "kitti"
     params = Params(args.encoder, 512, 80.0 if is_kitti else 10.0, "kitti" if is_kitti else "nyu")
-    B, H, W = args.batch, args.height, args.width
+    B, G, scaling = shard_plan(args, world)
+    H, W = args.height, args.width
     log("building model %s" % args.encoder)
     S = max(1, args.streams)
     while S > 1 and B % S:
@@ -293,6 +451,9 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         log("timed %d steps: %.3f ms/step" % (args.steps, 1e3 * elapsed / args.steps))
+        # frame 0 of what the LAST TIMED step produced (the replayed graph's static outputs): this is what the parity gate
+        # below compares with the CPU oracle -- the timed outputs themselves, not a fresh forward
+        timed_frame0 = [o[0:1].clone() for o in outs] if (rank == 0 and not args.decoder_only) else None
         if use_dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -322,7 +483,7 @@ def main():
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4),
                     "traffic": (pmc_traffic(dom) or {}).get("hbm_bytes_per_launch"),      # HBM bytes per launch (PMC) or null
-                    "traffic_unit": "bytes/launch", "traffic_source": (pmc_traffic(dom) or {}).get("source"),
+                    "traffic_unit": "bytes/launch", "traffic_source": pmc_traffic(dom),
                     "executed": round(executed, 2), "executed_frac": round(executed / PEAK_MFMA_F32_TFLOPS, 4),
                     "note": "achieved = algorithmic FLOP of the reference formulation / HIP-event time of isolated full-batch "
                             "launches (the timed region overlaps %d sub-batches of the same kernels); executed = FLOP the "
@@ -370,11 +531,12 @@ def main():
         line = {
             "metric": "depth frames/sec at B=16, 352x1216 KITTI input",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("BTS decoder hot path only" if args.decoder_only else "BtsModel.forward (encoder+decoder)")
-                       + ", %s, B=%d per GPU, 3x%dx%d fp32%s" % (args.encoder, B, H, W, baseline_config_label(args.encoder, B, H, W)),
-                       "batch_per_gpu": B, "global_batch": B * world, "image": "%dx%d" % (H, W),
+                       + ", %s, B=%d per GPU, 3x%dx%d fp32%s" % (args.encoder, B, H, W,
+                                                                  baseline_config_label(args.encoder, B, G, world, scaling, H, W)),
+                       "batch_per_gpu": B, "global_batch": G, "image": "%dx%d" % (H, W),
                        "parallelism": "dp%d batch-sharded, RCCL weight broadcast once%s" % (
                            world, ", all-gather of 5 depth maps per step" if gather else ""),
                        "hipgraph": graph is not None, "sub_batch_streams": S, "encoder_backend": args.encoder_backend,
@@ -393,11 +555,17 @@ def main():
                     forward()
                     torch.cuda.synchronize()
                     g2 = None
+                    outs2 = [None]
                     if use_graph:
                         g2 = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g2):
-                            outs2 = forward()
-                    run2 = (lambda: g2.replay()) if g2 is not None else forward
+                            outs2[0] = forward()
+
+                    def run2():
+                        if g2 is not None:
+                            g2.replay()
+                        else:
+                            outs2[0] = forward()
                     for _ in range(args.warmup):
                         run2()
                     torch.cuda.synchronize()
@@ -407,7 +575,7 @@ def main():
                     torch.cuda.synchronize()
                     el2 = time.perf_counter() - t1
                     if not args.decoder_only:
-                        emu_frame0 = [o[0:1].clone() for o in model(image[0:1], focal[0:1])]
+                        emu_frame0 = [o[0:1].clone() for o in outs2[0]]      # the timed outputs of this leg
                         torch.cuda.synchronize()
                 emu = {"what": "same workload, convolutions in bts_conv_desc.precision=1 (fp32 products emulated with six "
                                "bf16 MFMAs per block after a three-way operand split, fp32 accumulate); secondary number, "
@@ -422,21 +590,31 @@ def main():
                 ops.set_conv_precision(prev)
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")
-            frame0 = None
-            if not args.decoder_only and rank == 0:
-                with torch.no_grad():
-                    frame0 = [o[0:1].clone() for o in model(image[0:1], focal[0:1])]
-                torch.cuda.synchronize()
+            frame0 = timed_frame0             # outs[i][0:1] of the last timed step (graph replay or eager, as timed)
             line["cpu_baseline"], par, xpar = cpu_baseline(params, H, W, gpu_frame0=frame0,
                                                            extra_frame0={"bf16x3": emu_frame0} if emu_frame0 is not None else None)
             if par is not None:
+                par["compared"] = "outs[i][0:1] of the last timed step (%s) vs the CPU oracle on the same image and weights" % (
+                    "hipGraph replay" if graph is not None else "eager")
                 line["parity"] = par
             if emu is not None and "bf16x3" in xpar:
                 emu["parity"] = xpar["bf16x3"]
         if emu is not None:
+            if "parity" in emu and not emu["parity"]["ok"]:
+                emu["value"], emu["invalid"] = None, "parity gate of the emulated leg failed"
             line["emulated_fp32_bf16x3"] = emu
+        parity_failed = "parity" in line and not line["parity"]["ok"]
+        if parity_failed:                      # a fast kernel with wrong results is not a result: no clean-looking line
+            line["parity_failed"] = True
+            line["value_unverified"] = line["value"]
+            line["value"] = None
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        if parity_failed:
+            print("[bench] PARITY GATE FAILED: %r" % (line["parity"],), file=sys.stderr)
+            if use_dist:
+                dist.destroy_process_group()
+            sys.exit(3)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -55,6 +55,21 @@ class BtsHipError(RuntimeError):
     pass
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, common.h,
+    include/bts_hip.h): stamps profiles so that a counter value measured on older kernels is never quoted for newer ones."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "bts_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 

@@ -6,9 +6,14 @@ reports both in KB (1024 B); on gfx950 FETCH_SIZE counts wide streaming reads at
 import csv
 import glob
 import json
+import os
 import re
+import subprocess
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def short(name):
@@ -42,6 +47,14 @@ def main():
         w = write[k] * 1024 / 1e6 / max(nw[k], 1)
         out[k] = {"calls": nf[k], "fetch_MB_per_launch_x2": round(f, 3), "write_MB_per_launch": round(w, 3),
                   "hbm_MB_per_launch": round(f + w, 3)}
+    from bts_amd import _lib
+    commit = None
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        pass                                             # the GPU box snapshot has no .git: the source hash is the stamp
+    out["_meta"] = {"csrc_sha16": _lib.source_hash(), "commit": commit,
+                    "what": "HBM bytes per launch: 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE, separate --pmc passes"}
     json.dump(out, open(sys.argv[3], "w"), indent=0)
     for k, v in out.items():
         print(k, v)

@@ -1,0 +1,73 @@
+"""bench.py's multi-rank plumbing, on CPU: `--gpus N` must start N ranks itself (the reference: mp.spawn(main_worker,
+nprocs=ngpus), bts_main.py:843-847), report n_gpus = the ranks that really formed, and refuse -- non-zero exit, clear
+message -- to run with fewer ranks than asked for.  `--launcher-selftest` swaps RCCL for gloo and skips the hot path
+(which needs a GPU); everything else (launcher, rendezvous, shard plan, weight broadcast, barrier + max-over-ranks
+timing, packed all-gather, the single JSON line on stdout) is the code the N-GPU run uses."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _one_json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, stdout                      # the contract: exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra,scaling,per,total", [([], "weak", 16, 32), (["--global-batch", "64"], "strong", 32, 64)])
+def test_gpus2_starts_two_ranks(extra, scaling, per, total):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-selftest"] + extra, env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _one_json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["requested_gpus"] == 2
+    assert (line["scaling"], line["batch_per_gpu"], line["global_batch"]) == (scaling, per, total)
+    assert line["gather_ok"] and line["elapsed_is_max_over_ranks"] and line["shard"] == [0, per]
+
+
+def test_gpus2_without_two_gpus_fails_loudly():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node really has 2 GPUs")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2 requested" in r.stderr and r.stdout.strip() == ""      # no JSON line that could be mistaken for a result
+
+
+def test_under_torchrun_world_size_must_match_gpus():
+    port = _free_port()
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), BENCH, "--launcher-selftest"]
+    ok = subprocess.run(base + ["--gpus", "2"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    assert _one_json_line(ok.stdout)["n_gpus"] == 2
+    bad = subprocess.run(base[:9] + [str(_free_port())] + base[10:] + ["--gpus", "1"], env=_env(), capture_output=True,
+                         text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+def test_uneven_global_batch_is_rejected():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-selftest", "--global-batch", "7"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "not a multiple" in r.stderr
