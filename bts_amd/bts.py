@@ -29,6 +29,7 @@ from . import ops, train
 from ._lib import BtsHipError
 from . import encoders
 from .encoders import build_base_model
+from .workspace import PackCache, WorkspaceCache, tensor_fingerprint
 
 
 # ----------------------------------------------------------------- helpers kept from the reference API
@@ -84,9 +85,7 @@ def _bn_vecs(bn: nn.BatchNorm2d, n_pad: int) -> Tuple[torch.Tensor, torch.Tensor
     return ops.pad_vec(s, n_pad, 1.0), ops.pad_vec(b, n_pad, 0.0)
 
 
-def _param_key(module: nn.Module):
-    """Cheap fingerprint of a module's tensors: re-pack when load_state_dict/.cuda()/an optimizer touches them."""
-    return tuple((t.data_ptr(), t._version, str(t.device)) for t in list(module.parameters()) + list(module.buffers()))
+_param_key = tensor_fingerprint      # re-pack when load_state_dict / .cuda() / an optimizer touches a module's tensors
 
 
 def _nhwc_in(x: torch.Tensor, c_pad_to: int = 4) -> Tuple[torch.Tensor, int, int, int, int]:
@@ -117,21 +116,19 @@ class atrous_conv(nn.Sequential):
         self.atrous_conv = branch
         self.dilation = dilation
         self.apply_bn_first = apply_bn_first
-        self._pack = None
-        self._pack_key = None
+        self._packs = PackCache(self)        # shared with DataParallel replicas (bts_amd/workspace.py)
 
     def packed(self):
-        key = _param_key(self)
-        if self._pack is None or self._pack_key != key:
-            seq = self.atrous_conv.aconv_sequence
+        seq = self.atrous_conv.aconv_sequence
+
+        def build():
             w1, co1, k1 = ops.pack_conv_weight(seq[1].weight.detach())
             w2, co2, k2 = ops.pack_conv_weight(seq[4].weight.detach())
             pre = _bn_vecs(self.atrous_conv.first_bn, k1) if self.apply_bn_first else None   # k1 == c_in_ld
             e1 = _bn_vecs(seq[2], co1)
-            self._pack = dict(w1=w1, w2=w2, pre=pre, e1=e1, c_mid=seq[1].out_channels, c_out=seq[4].out_channels,
-                              c_in=seq[1].in_channels)
-            self._pack_key = key
-        return self._pack
+            return dict(w1=w1, w2=w2, pre=pre, e1=e1, c_mid=seq[1].out_channels, c_out=seq[4].out_channels,
+                        c_in=seq[1].in_channels)
+        return self._packs.get(seq[1].weight.device, build)
 
     def run_nhwc(self, x2d, B, h, w, mid2d, y2d):
         """Two launches: [BN]+ReLU -> 1x1 -> BN -> ReLU (mid), then dilated 3x3 into the y2d slice."""
@@ -161,19 +158,15 @@ class upconv(nn.Module):
         self.elu = nn.ELU()          # parameter-free; kept so the module tree prints like the reference's
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, bias=False)
         self.ratio = ratio
-        self._pack = None
-        self._pack_key = None
+        self._packs = PackCache(self)
 
     def packed(self):
         """Sub-pixel packing (four 2x2 kernels, ops.pack_upconv_subpixel) for ratio 2, plain 3x3 otherwise."""
-        key = _param_key(self)
-        if self._pack is None or self._pack_key != key:
+        def build():
             if self.ratio == 2:
-                self._pack = ops.pack_upconv_subpixel(self.conv.weight.detach())
-            else:
-                self._pack = ops.pack_conv_weight(self.conv.weight.detach())
-            self._pack_key = key
-        return self._pack
+                return ops.pack_upconv_subpixel(self.conv.weight.detach())
+            return ops.pack_conv_weight(self.conv.weight.detach())
+        return self._packs.get(self.conv.weight.device, build)
 
     def forward(self, x):
         if self.ratio not in (1, 2):
@@ -208,16 +201,11 @@ class reduction_1x1(nn.Sequential):
             else:
                 stack.add_module('plane_params', nn.Conv2d(cin, 3, kernel_size=1, bias=False))
         self.reduc = stack
-        self._pack = None
-        self._pack_key = None
+        self._packs = PackCache(self)
 
     def packed(self) -> torch.Tensor:
-        key = _param_key(self)
-        if self._pack is None or self._pack_key != key:
-            ws = [m.weight.detach() for m in self.reduc.modules() if isinstance(m, nn.Conv2d)]
-            self._pack = ops.pack_reduc_weights(ws)
-            self._pack_key = key
-        return self._pack
+        ws = [m.weight.detach() for m in self.reduc.modules() if isinstance(m, nn.Conv2d)]
+        return self._packs.get(ws[0].device, lambda: ops.pack_reduc_weights(ws))
 
     def run_nhwc(self, x2d, out, normalize):
         ops.reduc_forward_nhwc(x2d, self.c_in, self.c_first_out, self.packed(), self.max_depth, self.is_final,
@@ -293,17 +281,17 @@ class bts(nn.Module):
         ]
         for name, module in plan:
             setattr(self, name, module)
-        self._pack = None
-        self._pack_key = None
-        self._bufs: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        self._packs = PackCache(self)
+        self._bufs = WorkspaceCache(max_entries=8)      # per-shape NHWC workspaces; shared with replicas, graph-pinnable
 
     # ------------------------------------------------------------------ weight packing (lazy)
+    _OWN = ("bn5", "conv5", "bn4", "conv4", "bn4_2", "daspp_conv", "bn3", "conv3", "bn2", "conv2", "conv1", "get_depth")
+
     def packed(self):
-        own = [self.bn5, self.conv5, self.bn4, self.conv4, self.bn4_2, self.daspp_conv, self.bn3, self.conv3,
-               self.bn2, self.conv2, self.conv1, self.get_depth]
-        key = tuple(_param_key(m) for m in own)
-        if self._pack is not None and self._pack_key == key:
-            return self._pack
+        return self._packs.get(self.conv5[0].weight.device, self._build_pack,
+                               key_modules=lambda origin: [getattr(origin, n) for n in self._OWN])
+
+    def _build_pack(self):
         nf = self.num_features
         f = self.feat_out_channels
         P = {}
@@ -322,15 +310,14 @@ class bts(nn.Module):
         P["bn3"] = _bn_vecs(self.bn3, ops.round_up(nf // 4, 32))
         P["bn2"] = _bn_vecs(self.bn2, ops.round_up(nf // 8, 32))
         P["get_depth"] = self.get_depth[0].weight.detach().float().contiguous()
-        self._pack, self._pack_key = P, key
         return P
 
     # ------------------------------------------------------------------ NHWC workspace (per shape)
     def _workspace(self, B: int, H: int, W: int, device, slot: int = 0) -> Dict[str, torch.Tensor]:
         key = (B, H, W, str(device), slot)
-        ws = self._bufs.get(key)
-        if ws is not None:
-            return ws
+        return self._bufs.get(key, lambda: self._alloc_workspace(B, H, W, device))
+
+    def _alloc_workspace(self, B: int, H: int, W: int, device) -> Dict[str, torch.Tensor]:
         nf, f = self.num_features, self.feat_out_channels
         n32, n16, n8, n4, n2, n1 = [B * (H // s) * (W // s) for s in (32, 16, 8, 4, 2, 1)]
 
@@ -356,9 +343,6 @@ class bts(nn.Module):
             # scratch for split-K of under-filled launches (bts_conv_desc.splitk_ws): 8 splits x [n16, nf]
             splitk=torch.empty(8 * n16 * nf, dtype=torch.float32, device=device),
         )
-        if len(self._bufs) >= 8:
-            self._bufs.clear()
-        self._bufs[key] = ws
         return ws
 
     def skip_slots(self, ws):
@@ -539,7 +523,8 @@ class BtsModel(nn.Module):
         self.native_encoder = True          # set False to force the torch encoder (A/B, debugging)
         self.sub_batches = 4                # concurrent sub-batches (own HIP stream + workspace each); 1 = off
                                             # (MI355X, B=16: 1 -> 54.7, 2 -> 48.4, 4 -> 47.6, 8 -> 51.5 ms/step)
-        self._enc_hip = None
+        self._origin = [self]               # reaches DataParallel replicas through replicate()'s shallow __dict__ copy
+        self._enc_plans = {}                # device -> DenseNetHip / ResNetHip (packs + workspaces), shared with replicas
         self._side_streams = {}
 
     def _native_ok(self, x):
@@ -549,12 +534,18 @@ class BtsModel(nn.Module):
     def _forward_native(self, x, focal, slot, outs=None):
         from .encoder_hip import DenseNetHip, ResNetHip
         base = self.encoder.base_model
-        if self._enc_hip is None or getattr(self._enc_hip, "features", getattr(self._enc_hip, "model", None)) is not base:
-            self._enc_hip = ResNetHip(base) if isinstance(base, encoders.ResNet) else DenseNetHip(base)
+        src_base = self._origin[0].encoder.base_model      # a replica's packs are fingerprinted on the source model
+        cls = ResNetHip if isinstance(base, encoders.ResNet) else DenseNetHip
+        plan = self._enc_plans.get(str(x.device))
+        if plan is None or type(plan) is not cls or getattr(plan, "_src", None) is not src_base:
+            plan = cls(base, key_module=src_base)
+            plan._src = src_base
+            self._enc_plans[str(x.device)] = plan
+        plan.bind(base, key_module=src_base)
         B, _, H, W = x.shape
         dec = self.decoder
         ws = dec._workspace(B, H, W, x.device, slot)
-        r = self._enc_hip.run(x.float(), dec.skip_slots(ws), slot=slot)
+        r = plan.run(x.float(), dec.skip_slots(ws), slot=slot)
         # DenseNet: norm5 + ReLU become the prologue of the decoder's first conv; ResNet: layer4 is already ReLU'd
         return dec.forward_nhwc(ws, B, H, W, focal, r["dense"], r["norm5"], r["norm5"] is not None, outs=outs)
 
@@ -592,7 +583,8 @@ class BtsModel(nn.Module):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 lo, hi = i * b, (i + 1) * b
-                self._forward_native(x[lo:hi], focal_d[lo:hi], i, outs=[t[lo:hi] for t in full])
+                self._forward_native(x[lo:hi], focal_d[lo:hi] if isinstance(focal_d, torch.Tensor) else focal_d, i,
+                                     outs=[t[lo:hi] for t in full])
                 dec = self.decoder
                 mins.append(torch.stack([dec.lpg8x8.abs_min, dec.lpg4x4.abs_min, dec.lpg2x2.abs_min]))
         for i in range(S):

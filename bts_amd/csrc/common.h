@@ -1,6 +1,7 @@
 // Shared declarations for the gfx950 BTS hot-path kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "../../include/bts_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -15,3 +16,21 @@ __device__ __forceinline__ f32x16 mfma32x2(float a, float b, f32x16 c) {
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }      // nn.ELU(alpha=1)
 __device__ __forceinline__ float sigmoid1(float x) { return 1.f / (1.f + expf(-x)); }   // nn.Sigmoid
+
+// Raise a kernel's dynamic-LDS limit above the 64 KB default.  hipFuncAttributeMaxDynamicSharedMemorySize is a property
+// of (function, DEVICE): a process that drives several GPUs (nn.DataParallel: one Python thread per device,
+// bts_test.py:91) must set it on each of them.  `done` is one bit per device ordinal, owned by the kernel
+// instantiation's launcher; the only library state that is ever written after load, idempotent (setting the attribute
+// twice is harmless) and lock-free, so concurrent callers on any mix of devices and streams are safe.
+inline hipError_t bts_ensure_dynamic_lds(const void* kern, size_t bytes, std::atomic<unsigned long long>& done) {
+    if (bytes < 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = (dev >= 0 && dev < 64) ? 1ull << dev : 0ull;      // ordinals >= 64: set every time
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    if (bit) done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}

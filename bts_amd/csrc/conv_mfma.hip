@@ -29,6 +29,25 @@
 namespace {
 
 constexpr int BK = 32;
+
+// Tuning / A-B knobs from the environment, read ONCE (thread-safe function-local static) into an immutable struct:
+// nothing in this file mutates state after that, whichever thread, device or stream calls in.
+struct ConvKnobs {
+    int split_max; long split_below; long split_target;   // BTS_CONV_SPLITK / _BELOW / _TARGET
+    long lds_bytes;                                        // BTS_CONV_LDS_KB: inflate LDS to cap workgroups per CU (0 = off)
+    int no48, force_bm;                                    // BTS_CONV_NO48, BTS_CONV_BM
+    int precision, emu_sb;                                 // BTS_CONV_PRECISION, BTS_CONV_EMU_SB (-1 = unset)
+    int w8, w8s;                                           // BTS_CONV_W8, BTS_CONV_W8S
+};
+inline long env_long(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
+const ConvKnobs& knobs() {
+    static const ConvKnobs k = {(int)env_long("BTS_CONV_SPLITK", 8), env_long("BTS_CONV_SPLITK_BELOW", 700),
+                                env_long("BTS_CONV_SPLITK_TARGET", 1024), env_long("BTS_CONV_LDS_KB", 0) * 1024,
+                                (int)env_long("BTS_CONV_NO48", 0), (int)env_long("BTS_CONV_BM", 0),
+                                (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
+                                (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1)};
+    return k;
+}
 // floats per LDS row (32 + pad), chosen per MFMA shape so that the 16 rows a ds_read_b128 lane group touches
 // land in 16 distinct 16-B bank slots: 36 (slot = 9*row) for the 32x32 lane map, 40 (slot = 10*row + k-quarter)
 // for the 16x16 one -- 36 is 2-way conflicted there (SQ_LDS_BANK_CONFLICT, profiles/r01_pmc_mfma.json)
@@ -583,12 +602,12 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     // bits, must not depend on how many frames share the launch (frames are independent, bts.py:223-293).
     const int nit_all = a.k_pad / BK;
     a.ksplit = 1; a.its_per_split = nit_all; a.ws_ld = (a.c_out + 3) & ~3;
-    static const int split_max = getenv("BTS_CONV_SPLITK") ? atoi(getenv("BTS_CONV_SPLITK")) : 8;
-    static const long split_below = getenv("BTS_CONV_SPLITK_BELOW") ? atol(getenv("BTS_CONV_SPLITK_BELOW")) : 700;
+    const int split_max = knobs().split_max;
+    const long split_below = knobs().split_below;
     if (a.n_classes == 1 && a.ws != nullptr && split_max > 1) {
         const long tiles64 = ((8L * a.H * a.W + 63) / 64) * a.n_ntiles;     // 64-row tiles of a nominal 8-frame launch
         if (tiles64 < split_below) {
-            static const long split_target = getenv("BTS_CONV_SPLITK_TARGET") ? atol(getenv("BTS_CONV_SPLITK_TARGET")) : 1024;
+            const long split_target = knobs().split_target;
             long sp = split_target / tiles64;
             if (sp > split_max) sp = split_max;
             if (sp > nit_all / 4) sp = nit_all / 4;
@@ -602,28 +621,17 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     if (nwg > 0x7fffffffL) return BTS_ERR_INVALID;
     size_t lds = PREC == 0 ? (size_t)2 * (BM + BN) * LdsLd<MF>::value * sizeof(float)
                            : (size_t)(PREC == 2 ? 1 : 2) * 3 * (BM + BN) * EMU_ROW_BYTES;
-    if (const char* f = getenv("BTS_CONV_LDS_KB")) {   // tuning aid: inflate LDS to limit workgroups per CU
-        const size_t v = (size_t)atoi(f) * 1024;
-        if (v > lds && v <= 160 * 1024) lds = v;
-    }
+    if ((size_t)knobs().lds_bytes > lds && knobs().lds_bytes <= 160 * 1024) lds = (size_t)knobs().lds_bytes;
     hipError_t e;
     if (nchw) {
         auto k = conv_fwd_kernel<BM, BN, WM, WN, MF, true, PREC>;
-        static size_t lds_allowed = 64 * 1024;               // per instantiation: raise the dynamic-LDS limit once
-        if (lds > lds_allowed) {
-            e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            lds_allowed = lds;
-        }
+        static std::atomic<unsigned long long> lds_set{0};    // per instantiation: one bit per device (bts_ensure_dynamic_lds)
+        if ((e = bts_ensure_dynamic_lds((const void*)k, lds, lds_set)) != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, a);
     } else {
         auto k = conv_fwd_kernel<BM, BN, WM, WN, MF, false, PREC>;
-        static size_t lds_allowed = 64 * 1024;               // per instantiation: raise the dynamic-LDS limit once
-        if (lds > lds_allowed) {
-            e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            lds_allowed = lds;
-        }
+        static std::atomic<unsigned long long> lds_set{0};
+        if ((e = bts_ensure_dynamic_lds((const void*)k, lds, lds_set)) != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, s, a);
     }
     if (a.ksplit > 1) {
@@ -648,7 +656,7 @@ void choose_tile(long M, int c_out, int* bm, int* bn) {
         const double cost = (double)((c_out + cand[i] - 1) / cand[i] * cand[i]) * eff[i];
         if (cost < best) { best = cost; *bn = cand[i]; }
     }
-    if (const char* f = getenv("BTS_CONV_NO48")) { if (atoi(f) && *bn == 48) *bn = 64; }
+    if (knobs().no48 && *bn == 48) *bn = 64;
     *bm = 128;
     if (*bn != 32) {
         const long nt = (c_out + *bn - 1) / *bn;
@@ -657,8 +665,8 @@ void choose_tile(long M, int c_out, int* bm, int* bn) {
         const double t64 = (double)((wg64 + 255) / 256) * 64.0 * 1.05;
         if (t64 < t128) *bm = 64;
     }
-    if (const char* f = getenv("BTS_CONV_BM")) {       // tuning aid: force the row tile (64 / 128)
-        const int v = atoi(f);
+    {                                                  // tuning aid: force the row tile (64 / 128)
+        const int v = knobs().force_bm;
         if ((v == 64 && *bn != 32) || v == 128) *bm = v;
     }
 }
@@ -734,7 +742,7 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     choose_tile(a.M * a.n_classes, d->c_out, &bm, &bn);
     // precision: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products), 1 = fp32 emulated on the bf16 matrix cores
     // (three-way split, six products; see split_store).  BTS_CONV_PRECISION overrides the descriptor (A/B runs).
-    static const int prec_env = getenv("BTS_CONV_PRECISION") ? atoi(getenv("BTS_CONV_PRECISION")) : -1;
+    const int prec_env = knobs().precision;
     const int prec = prec_env >= 0 ? prec_env : d->precision;
     if (prec != 0 && prec != 1) return BTS_ERR_INVALID;
     if (prec == 1) {
@@ -744,7 +752,7 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
         // workgroups per CU (total over the decoder layers 134.7 vs 126.6 TFLOP/s-equivalent).  BTS_CONV_EMU_SB=0 = double.
         // (Forcing a third workgroup per CU with an 80-VGPR cap on the narrow tiles: same layer rates, whole model
         // 39.7 vs 38.3 ms -- dropped.)
-        static const int emu_sb_env = getenv("BTS_CONV_EMU_SB") ? atoi(getenv("BTS_CONV_EMU_SB")) : -1;
+        const int emu_sb_env = knobs().emu_sb;
         const int emu_sb = emu_sb_env >= 0 ? emu_sb_env : 1;
         if (emu_sb) {                                  // one LDS buffer: half the footprint, two workgroups per CU
             if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4, 32, 2>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 4, 32, 2>(a, nchw, s, wsf);
@@ -758,8 +766,7 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if (bn == 48) return bm == 128 ? launch_conv<128, 48, 4, 1, 16>(a, nchw, s, wsf) : launch_conv<64, 48, 4, 1, 16>(a, nchw, s, wsf);
     // 8-wave workgroups (two waves per SIMD from the same tile) for the 128-row tiles: +2 % end to end over the
     // 4-wave layout on MI355X (more waves to cover each other's staging); BTS_CONV_W8=0 selects the 4-wave kernels
-    static const int w8 = getenv("BTS_CONV_W8") ? atoi(getenv("BTS_CONV_W8")) : 1;
-    static const int w8s = getenv("BTS_CONV_W8S") ? atoi(getenv("BTS_CONV_W8S")) : 1;
+    const int w8 = knobs().w8, w8s = knobs().w8s;
     if (bn == 128) {
         if (bm == 128) return w8 ? launch_conv<128, 128, 2, 4>(a, nchw, s, wsf) : launch_conv<128, 128, 2, 2>(a, nchw, s, wsf);
         return w8s ? launch_conv<64, 128, 2, 4>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 2>(a, nchw, s, wsf);

@@ -34,21 +34,27 @@ __device__ __forceinline__ float lpg_clamp(float d) {
 }
 
 // block-min of |den| then ONE atomic per block: same-address atomics serialise in L2 (~12 ns each on
-// MI355X), so blocks are fat (16 waves) and the grid is capped at 512.  abs(den) >= 0 so the uint order is
-// the float order.
+// MI355X), so blocks are fat (16 waves) and the grid is capped at 512.
+// NaN: the reference's `torch.abs(divided).min()` (bts.py:167) returns NaN as soon as one denominator is NaN, and
+// bts_main.py:484-486 logs abs_min precisely to hunt NaNs -- so a NaN must win the reduction.  fminf drops NaNs;
+// the reduction therefore runs on int32 KEYS: a non-negative float's bit pattern as a signed int keeps the float
+// order, and "saw a NaN" is the negative key 0xffc00000 (a quiet NaN with the sign bit set), which is below every
+// real key and still reads back as NaN from the caller's float scalar.
 constexpr int LPG_ROWS = 16;                       // block = 64 x 16 threads
-__device__ __forceinline__ void publish_abs_min(float m, unsigned* abs_min_bits) {
-    __shared__ float wave_min[LPG_ROWS];
+constexpr int LPG_NAN_KEY = (int)0xffc00000u;
+__device__ __forceinline__ void publish_abs_min(float m, bool saw_nan, int* abs_min_key) {
+    __shared__ int wave_min[LPG_ROWS];
+    int k = saw_nan ? LPG_NAN_KEY : __float_as_int(m);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+    for (int off = 32; off > 0; off >>= 1) k = min(k, __shfl_xor(k, off, 64));
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    if ((tid & 63) == 0) wave_min[tid >> 6] = m;
+    if ((tid & 63) == 0) wave_min[tid >> 6] = k;
     __syncthreads();
     if (tid < 64) {
-        m = tid < LPG_ROWS ? wave_min[tid] : __uint_as_float(0x7f800000u);
+        k = tid < LPG_ROWS ? wave_min[tid] : 0x7f800000;
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
-        if (tid == 0) atomicMin(abs_min_bits, __float_as_uint(m));
+        for (int off = 8; off > 0; off >>= 1) k = min(k, __shfl_xor(k, off, 64));
+        if (tid == 0) atomicMin(abs_min_key, k);
     }
 }
 
@@ -59,11 +65,12 @@ __global__ __launch_bounds__(64 * LPG_ROWS) void lpg_fwd_kernel(const float* __r
                                                       int normalize, float max_depth,
                                                       float* __restrict__ out, float* __restrict__ ds_out,
                                                       int ds_factor, long ds_pix_stride,
-                                                      unsigned* __restrict__ abs_min_bits) {
+                                                      int* __restrict__ abs_min_bits) {
     const int W = w * K, H = h * K;
     const int W4 = W / V;                        // V = 4 when W % 4 == 0 (16-byte stores), else 1
     const int nrows = B * H;
     float amin = __uint_as_float(0x7f800000u);
+    bool saw_nan = false;
     // block = 64 x 16: a wave walks one output row in 64-wide strides (coalesced 1 KiB stores), so the
     // (b, r) decode costs one division per row instead of two per element.
     [[maybe_unused]] const float inv_scale_den = max_depth;         // FUSED: depth/max_depth == n4 / (den * max_depth)
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(64 * LPG_ROWS) void lpg_fwd_kernel(const float* __r
                 const float u = ((float)(c % K) - (float)(K - 1) * 0.5f) / (float)K;  // bts.py:157-158
                 float d = lpg_den(n1, n2, n3, u, v);                                   // bts.py:166
                 amin = fminf(amin, fabsf(d));                                          // bts.py:167
+                saw_nan |= d != d;
                 d = lpg_clamp(d);
                 float y = n4 / d;                                                     // bts.py:173
                 if (FUSED) y = y / max_depth;                                         // bts.py:255
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(64 * LPG_ROWS) void lpg_fwd_kernel(const float* __r
             }
         }
     }
-    if (abs_min_bits != nullptr) publish_abs_min(amin, abs_min_bits);
+    if (abs_min_bits != nullptr) publish_abs_min(amin, saw_nan, abs_min_bits);
 }
 
 // Lean kernel for the decoder pipeline's case (planes already normalised by the reduction epilogue, W % 4 == 0,
@@ -134,11 +142,12 @@ __global__ __launch_bounds__(64 * LPG_ROWS) void lpg_fused_lean_kernel(const flo
                                                                        int h, int w, float max_depth,
                                                                        float* __restrict__ out, float* __restrict__ ds_out,
                                                                        int ds_factor, int ds_pix_stride,
-                                                                       unsigned* __restrict__ abs_min_bits) {
+                                                                       int* __restrict__ abs_min_bits) {
     const int W = w * K, W4 = W >> 2;
     constexpr float invK = 1.0f / (float)K;
     constexpr int CELLS = K >= 4 ? 1 : 2;
     float amin = __uint_as_float(0x7f800000u);
+    bool saw_nan = false;
     for (int row = blockIdx.x * LPG_ROWS + threadIdx.y; row < nrows; row += gridDim.x * LPG_ROWS) {
         const int b = row / H, r = row - b * H;
         const int cr = r / K;
@@ -160,6 +169,7 @@ __global__ __launch_bounds__(64 * LPG_ROWS) void lpg_fused_lean_kernel(const flo
                 for (int i = 0; i < 4 / CELLS; ++i) {
                     float d = fmaf(q.x, u0 + (float)i * invK, base);        // n1*u + n2*v + n3   (bts.py:166)
                     amin = fminf(amin, fabsf(d));                           // bts.py:167
+                    saw_nan |= d != d;
                     d = lpg_clamp(d);                                       // bts.py:168-171
                     res[ci * (4 / CELLS) + i] = q.w * __builtin_amdgcn_rcpf(d * max_depth);   // bts.py:173,255
                 }
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(64 * LPG_ROWS) void lpg_fused_lean_kernel(const flo
             }
         }
     }
-    if (abs_min_bits != nullptr) publish_abs_min(amin, abs_min_bits);
+    if (abs_min_bits != nullptr) publish_abs_min(amin, saw_nan, abs_min_bits);
 }
 
 template <bool PLANAR, bool FUSED>
@@ -185,7 +195,7 @@ int launch_lpg(const float* plane, int B, int h, int w, int k, int normalize, fl
     if (k != 1 && k != 2 && k != 4 && k != 8) return BTS_ERR_UNSUPPORTED;
     if (ds_out && (ds_factor <= 0 || (h * k) % ds_factor || (w * k) % ds_factor)) return BTS_ERR_INVALID;
     if (FUSED && !(max_depth > 0.f)) return BTS_ERR_INVALID;
-    unsigned* bits = reinterpret_cast<unsigned*>(abs_min);
+    int* bits = reinterpret_cast<int*>(abs_min);
     if (bits) {
         hipError_t e = hipMemsetD32Async((hipDeviceptr_t)bits, 0x7f800000, 1, s);
         if (e != hipSuccess) return (int)e;

@@ -141,10 +141,8 @@ int launch_reduc(const float* x, long stride, long npix, const float* w_frag, lo
     if (w_frag_floats != NW * 4) return BTS_ERR_INVALID;
     const size_t lds = (size_t)NW * 16;
     auto kern = reduc_fwd_kernel<C0, M0, FINAL>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
+    static std::atomic<unsigned long long> lds_set{0};     // per instantiation: one bit per device (common.h)
+    if (hipError_t e = bts_ensure_dynamic_lds((const void*)kern, lds, lds_set); e != hipSuccess) return (int)e;
     const long ntiles = (npix + 31) / 32;
     const int per_cu = lds > 80 * 1024 ? 1 : 2;
     long blocks = (ntiles + 7) / 8;

@@ -230,12 +230,8 @@ int launch_wgrad(WgradArgs a, long split, float* dw, float* ws, hipStream_t s) {
     a.out = split > 1 ? ws : dw;
     const size_t lds_bytes = (size_t)2 * WBK * (BM + BN) * sizeof(float);
     auto kern = conv_wgrad_kernel<BM, BN, WM, WN>;
-    static bool attr_done = false;     // per instantiation
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return (int)hipGetLastError();
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> lds_set{0};     // per instantiation: one bit per device (common.h)
+    if (hipError_t e = bts_ensure_dynamic_lds((const void*)kern, lds_bytes, lds_set); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)split, (unsigned)a.n_bundles), dim3(256), lds_bytes, s, a);
     if (split > 1) {
         const long count4 = per / 4;      // N % 4 == 0
@@ -255,7 +251,8 @@ struct WgradPlan { int variant; long split; };
 inline WgradPlan plan_wgrad(int c_out, int N, long M, long ws_floats, bool have_ws, int n_bundles) {
     static const int bm[4] = {128, 64, 32, 64}, bn[4] = {128, 128, 128, 64};
     static const double eff[4] = {1.0, 0.9, 0.75, 0.8};
-    static const long target = getenv("BTS_WGRAD_TARGET") ? atol(getenv("BTS_WGRAD_TARGET")) : 768;
+    static const long target = getenv("BTS_WGRAD_TARGET") ? atol(getenv("BTS_WGRAD_TARGET")) : 768;   // immutable once read
+    static const int force_variant = getenv("BTS_WGRAD_VARIANT") ? (atoi(getenv("BTS_WGRAD_VARIANT")) & 3) : -1;
     const long per = (long)c_out * N * n_bundles;
     long max_split = M / (4 * WBK);
     if (max_split > 1024) max_split = 1024;
@@ -277,7 +274,7 @@ inline WgradPlan plan_wgrad(int c_out, int N, long M, long ws_floats, bool have_
         const double score = useful * eff[v] * fill * in_bytes / (in_bytes + partial_bytes);
         if (score > best_score * 1.0001) { best_score = score; best = {v, split}; }
     }
-    if (const char* f = getenv("BTS_WGRAD_VARIANT")) best.variant = atoi(f) & 3;
+    if (force_variant >= 0) best.variant = force_variant;
     return best;
 }
 

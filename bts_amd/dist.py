@@ -23,27 +23,32 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 64 << 20):
-    """Broadcast parameters + buffers from ``src`` in flat fp32 buckets (one-time start-up cost)."""
+    """Broadcast parameters + buffers from ``src`` in flat buckets (one-time start-up cost).
+
+    The received values are copied into the parameters THEMSELVES under ``no_grad`` (not through ``.data``), so every
+    tensor's ``_version`` bumps and the packed-weight caches / captured graphs keyed on (data_ptr, _version) rebuild:
+    a rank that ran a warm-up forward before the broadcast does not keep computing with its pre-broadcast packs."""
     if not dist.is_initialized():
         return
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    tensors = list(module.parameters()) + list(module.buffers())
     by_dtype = {}
     for t in tensors:
         by_dtype.setdefault(t.dtype, []).append(t)
-    for dtype, ts in by_dtype.items():
-        bucket, size = [], 0
-        for t in ts + [None]:
-            if t is not None:
-                bucket.append(t)
-                size += t.numel() * t.element_size()
-            if bucket and (t is None or size >= bucket_bytes):
-                flat = torch.cat([x.reshape(-1) for x in bucket])
-                dist.broadcast(flat, src=src)
-                off = 0
-                for x in bucket:
-                    x.copy_(flat[off:off + x.numel()].view_as(x))
-                    off += x.numel()
-                bucket, size = [], 0
+    with torch.no_grad():
+        for dtype, ts in by_dtype.items():
+            bucket, size = [], 0
+            for t in ts + [None]:
+                if t is not None:
+                    bucket.append(t)
+                    size += t.numel() * t.element_size()
+                if bucket and (t is None or size >= bucket_bytes):
+                    flat = torch.cat([x.detach().reshape(-1) for x in bucket])
+                    dist.broadcast(flat, src=src)
+                    off = 0
+                    for x in bucket:
+                        x.copy_(flat[off:off + x.numel()].view_as(x))
+                        off += x.numel()
+                    bucket, size = [], 0
 
 
 def all_gather_depths(outs: Sequence[torch.Tensor], n_maps: int = 5, async_op: bool = False):

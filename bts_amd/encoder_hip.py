@@ -26,6 +26,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .workspace import WorkspaceCache, invalidate_packs, tensor_fingerprint, _generation
 
 
 def _bn_vecs(bn: nn.BatchNorm2d, n_pad: int):
@@ -34,17 +35,18 @@ def _bn_vecs(bn: nn.BatchNorm2d, n_pad: int):
 
 
 def _key(module: nn.Module):
-    return tuple((t.data_ptr(), t._version, str(t.device)) for t in list(module.parameters()) + list(module.buffers()))
+    return (_generation[0],) + tensor_fingerprint(module)
 
 
 class DenseNetHip:
     """Execution plan for ``encoders.densenet_features`` (torchvision ``DenseNet.features``)."""
 
-    def __init__(self, features: nn.Sequential):
+    def __init__(self, features: nn.Sequential, key_module: Optional[nn.Module] = None):
         self.features = features
+        self.key_module = key_module if key_module is not None else features   # whose tensors fingerprint the packs
         self._pack = None
         self._pack_key = None
-        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        self._ws = WorkspaceCache(max_entries=8)
         f = features
         self.c_stem = f.conv0.out_channels
         self.blocks = [m for n, m in f.named_children() if n.startswith("denseblock")]
@@ -55,9 +57,20 @@ class DenseNetHip:
         self.c_in = [b.num_input_features for b in self.blocks]
         self.c_out = [b.num_input_features + len(b) * b.growth_rate for b in self.blocks]
 
+    def bind(self, features: nn.Sequential, key_module: Optional[nn.Module] = None):
+        """Point the plan at another instance of the same network -- a DataParallel replica, re-created on every
+        forward (bts_test.py:91) -- without dropping packs or workspaces: the packs are fingerprinted on
+        ``key_module`` (the SOURCE model's tensors), which the replica's freshly broadcast copies equal."""
+        if features is not self.features:
+            self.features = features
+            self.blocks = [m for n, m in features.named_children() if n.startswith("denseblock")]
+            self.transitions = [m for n, m in features.named_children() if n.startswith("transition")]
+        self.key_module = key_module if key_module is not None else features
+        return self
+
     # ------------------------------------------------------------------------- packing
     def packed(self):
-        key = _key(self.features)
+        key = _key(self.key_module)
         if self._pack is not None and self._pack_key == key:
             return self._pack
         f = self.features
@@ -85,10 +98,9 @@ class DenseNetHip:
 
     # ----------------------------------------------------------------------- workspace
     def _workspace(self, B, H, W, device, slot=0):
-        key = (B, H, W, str(device), slot)
-        ws = self._ws.get(key)
-        if ws is not None:
-            return ws
+        return self._ws.get((B, H, W, str(device), slot), lambda: self._alloc_workspace(B, H, W, device))
+
+    def _alloc_workspace(self, B, H, W, device):
         n = [B * (H // s) * (W // s) for s in (1, 2, 4, 8, 16, 32)]
 
         def z(npix, c):
@@ -101,9 +113,6 @@ class DenseNetHip:
             ws["blk%d" % i] = z(n[2 + i], self.c_out[i])
         for i in range(3):
             ws["pool%d" % i] = z(n[3 + i], self.c_out[i])
-        if len(self._ws) >= 8:
-            self._ws.clear()
-        self._ws[key] = ws
         return ws
 
     # ----------------------------------------------------------------------------- run
@@ -180,18 +189,27 @@ class ResNetHip:
     FLOPs on the two shallow stages only.  The taps the decoder needs (relu, layer1..3; reference bts.py:318-338) are
     written straight into its concat buffers; layer4's output is the decoder's dense input."""
 
-    def __init__(self, model: nn.Module):
+    def __init__(self, model: nn.Module, key_module: Optional[nn.Module] = None):
         self.model = model
+        self.key_module = key_module if key_module is not None else model
         self._pack = None
         self._pack_key = None
-        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        self._ws = WorkspaceCache(max_entries=8)
         self.layers = [model.layer1, model.layer2, model.layer3, model.layer4]
         self.c_stem = model.conv1.out_channels
         self.c_out = [l[-1].conv3.out_channels for l in self.layers]
         self.width = [l[0].conv2.out_channels for l in self.layers]
 
+    def bind(self, model: nn.Module, key_module: Optional[nn.Module] = None):
+        """See DenseNetHip.bind."""
+        if model is not self.model:
+            self.model = model
+            self.layers = [model.layer1, model.layer2, model.layer3, model.layer4]
+        self.key_module = key_module if key_module is not None else model
+        return self
+
     def packed(self):
-        key = _key(self.model)
+        key = _key(self.key_module)
         if self._pack is not None and self._pack_key == key:
             return self._pack
         m = self.model
@@ -221,10 +239,9 @@ class ResNetHip:
         return P
 
     def _workspace(self, B, H, W, device, slot=0):
-        key = (B, H, W, str(device), slot)
-        ws = self._ws.get(key)
-        if ws is not None:
-            return ws
+        return self._ws.get((B, H, W, str(device), slot), lambda: self._alloc_workspace(B, H, W, device))
+
+    def _alloc_workspace(self, B, H, W, device):
         n = [B * (H // s) * (W // s) for s in (1, 2, 4, 8, 16, 32)]
 
         def z(npix, c):
@@ -239,9 +256,6 @@ class ResNetHip:
             ws["idn_%d" % li] = z(px, self.c_out[li])
             ws["a_%d" % li] = z(px, self.c_out[li])
             ws["b_%d" % li] = z(px, self.c_out[li])
-        if len(self._ws) >= 8:
-            self._ws.clear()
-        self._ws[key] = ws
         return ws
 
     def run(self, x: torch.Tensor, skip_dst: Optional[List[Optional[torch.Tensor]]] = None, slot: int = 0):

@@ -13,7 +13,11 @@
  *  - return value: 0 = ok, >0 = a hipError_t from the launch, <0 = BTS_ERR_* (bad
  *    arguments); errors are raised by the wrapper, never thrown across the ABI
  *    (cf. OP_REQUIRES / errors::InvalidArgument in local_planar_guidance.cc:36-44,123);
- *  - the library holds no global mutable state and is re-entrant per (device, stream).
+ *  - re-entrant per (device, stream): every entry point works on the calling thread's current device and the given
+ *    stream.  The library keeps no mutable state between calls except one idempotent, lock-free cache: "the
+ *    dynamic-LDS limit of kernel K has been raised on device D" (a bit per device ordinal; the attribute is per
+ *    device, so a process driving several GPUs -- nn.DataParallel, bts_test.py:91 -- gets it set on each).  Tuning
+ *    knobs (BTS_CONV_*, BTS_WGRAD_* environment variables) are read once into immutable values.
  */
 #ifndef BTS_HIP_H_
 #define BTS_HIP_H_

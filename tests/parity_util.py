@@ -135,39 +135,62 @@ def oracle_train_step(dtype=torch.float32):
                 param_grads=grads, state=state)
 
 
+class ErrDict(dict):
+    """{tensor name: relative error} that also remembers each tensor's element count (``sizes``)."""
+    sizes: dict = {}
+
+
 def grad_error_report(got: dict, ref: dict):
-    """{name: max abs error / max abs ref} plus the global relative L2 error over all tensors."""
-    per, num, den = {}, 0.0, 0.0
+    """{name: max abs error / max abs ref} (an ErrDict carrying the tensors' sizes) plus the global relative L2 error
+    over all tensors."""
+    per, num, den = ErrDict(), 0.0, 0.0
+    per.sizes = {}
     for n, r in ref.items():
         r = np.asarray(r, dtype=np.float64)
         d = np.asarray(got[n], dtype=np.float64) - r
         per[n] = float(np.abs(d).max() / max(np.abs(r).max(), 1e-300))
+        per.sizes[n] = int(r.size)
         num += float((d ** 2).sum())
         den += float((r ** 2).sum())
     return per, float(np.sqrt(num / max(den, 1e-300)))
 
 
-def assert_grads_close(per: dict, global_l2: float, what: str, typical=2e-3, worst=0.1, l2=2e-3, fp32_floor=None):
+LARGE_TENSOR = 10_000        # elements: above this a single flipped ReLU cannot move a tensor's max error by percents
+
+
+def assert_grads_close(per: dict, global_l2: float, what: str, typical=2e-3, worst=0.1, l2=2e-3, fp32_floor=None,
+                       worst_large=2e-2):
     """The bar for gradients that come out of a DIFFERENT fp32 summation order than the reference's.
 
     A training step through batch-statistic BN + ReLU on the 48..192-sample maps of the small case is not smooth:
     a pre-activation that is 1e-7 from zero flips its ReLU mask under any reordering, and one flipped element moves
     a small gradient tensor (first_bn.bias, |g| ~ 7e-4) by percents.  The CPU fp32 oracle shows exactly this against
     its own fp64 run (up to 4e-2 on single tensors, which tensor varies run to run).  So: at least 90 % of the
-    tensors within ``typical`` (max abs error / max abs value), every tensor within ``worst`` (a wrong term, sign or
-    border shows up as O(1)), and the whole gradient -- what the optimiser sees -- within ``l2`` in relative L2.
+    tensors within ``typical`` (max abs error / max abs value); every SMALL tensor (< LARGE_TENSOR elements: biases,
+    BN vectors, the reduction stacks' last layers) within ``worst``; every LARGE tensor (conv weights, feature
+    gradients -- where one flipped element drowns in the tensor's scale, so a wrong border term or tap cannot hide)
+    within ``worst_large``; and the whole gradient -- what the optimiser sees -- within ``l2`` in relative L2.
     ``fp32_floor`` = (per, global_l2) of the CPU fp32 oracle against the same fp64 yardstick: where fp32 arithmetic
-    itself is further from exact than the flat bars (deep encoder + decoder step), the bars become 2x its figures."""
+    itself is further from exact than the flat bars (deep encoder + decoder step), a bar becomes 2x the floor's figure
+    for the same class of tensors.  Failures name the worst tensors with their sizes."""
+    sizes = getattr(per, "sizes", {})
     errs = np.array(sorted(per.values()))
     q90 = errs[int(0.9 * (len(errs) - 1))]
     if fp32_floor is not None:
-        f = np.array(sorted(fp32_floor[0].values()))
+        fper, fl2 = fp32_floor
+        fsizes = getattr(fper, "sizes", sizes)
+        f = np.array(sorted(fper.values()))
         typical = max(typical, 2.0 * f[int(0.9 * (len(f) - 1))])
-        worst = max(worst, 2.0 * f[-1])
-        l2 = max(l2, 2.0 * fp32_floor[1])
-    bad = sorted(((e, n) for n, e in per.items()), reverse=True)[:3]
-    assert q90 <= typical, (what, "90th percentile", q90, bad)
-    assert errs[-1] <= worst, (what, "worst tensor", bad)
+        small = [e for n, e in fper.items() if fsizes.get(n, 0) < LARGE_TENSOR]
+        large = [e for n, e in fper.items() if fsizes.get(n, 0) >= LARGE_TENSOR]
+        worst = max(worst, 2.0 * max(small)) if small else worst
+        worst_large = max(worst_large, 2.0 * max(large)) if large else worst_large
+        l2 = max(l2, 2.0 * fl2)
+    bad = [(round(e, 5), n, sizes.get(n)) for e, n in sorted(((e, n) for n, e in per.items()), reverse=True)[:3]]
+    assert q90 <= typical, (what, "90th percentile", q90, "worst (err, tensor, elements):", bad)
+    for n, e in per.items():
+        cap = worst_large if sizes.get(n, 0) >= LARGE_TENSOR else worst
+        assert e <= cap, (what, "tensor %s (%s elements): error %.3g > %.3g" % (n, sizes.get(n), e, cap), bad)
     assert global_l2 <= l2, (what, "global relative L2", global_l2, bad)
 
 

@@ -34,7 +34,11 @@ def _worker(rank, world, port, out_dir):
         with torch.no_grad():
             m[1].running_mean.normal_()
             m[1].num_batches_tracked.fill_(rank + 5)
+        versions = [x._version for x in list(m.parameters()) + list(m.buffers())]
         bdist.broadcast_module(m, src=0, bucket_bytes=256)      # tiny buckets -> several collectives
+        # the copy goes into the tensors themselves, so every _version bumps: packed-weight caches and captured graphs
+        # keyed on (data_ptr, _version) rebuild after a broadcast that follows a warm-up forward
+        assert all(x._version > v for x, v in zip(list(m.parameters()) + list(m.buffers()), versions))
         flat = torch.cat([t.detach().double().reshape(-1) for t in list(m.parameters()) + list(m.buffers())])
         gathered = [torch.zeros_like(flat) for _ in range(world)]
         dist.all_gather(gathered, flat)

@@ -284,6 +284,6 @@ def test_btsmodel_resnext101_fused_forward_vs_cpu():
     mg = mg.cuda()
     with torch.no_grad():
         got = mg(x.cuda(), focal.cuda())
-    assert mg._enc_hip is not None and type(mg._enc_hip).__name__ == "ResNetHip"
+    assert [type(pl).__name__ for pl in mg._enc_plans.values()] == ["ResNetHip"]
     rep = check_outputs(got, ref_outs, inter, rel_tol=5e-4, what="fused ResNeXt101 BtsModel")
     print("fused ResNeXt101 model max-rel:", rep)

@@ -1,0 +1,350 @@
+"""Round-2 GPU tests: the holes the round-1 review named (full-size encoders, BASELINE configs[3]/[4] per-GPU
+workloads) and the host-side contracts around the kernels (graphs vs workspaces / weight changes, DataParallel
+replicas, threads, NaN telemetry)."""
+import copy
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from bts_amd import synth
+from oracle import bts_oracle as O
+from parity_util import (CONFIGS, Params, assert_grads_close, build_hip_decoder, check_outputs, grad_error_report,
+                         hip_run, make_inputs, oracle_run, t)
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(enc, dataset="kitti", seed=3, max_depth=None):
+    from bts_amd import bts as M
+    torch.manual_seed(seed)
+    md = max_depth if max_depth is not None else (80.0 if dataset == "kitti" else 10.0)
+    m = M.BtsModel(Params(enc, 512, md, dataset))
+    sd = {k: (torch.tensor(v) if np.ndim(v) == 0 else t(v))
+          for k, v in synth.decoder_state(synth.ENCODER_CHANNELS[enc], 512, 0).items()}
+    m.decoder.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+# ------------------------------------------------------------------------------------------------ NaN telemetry
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_abs_min_propagates_nan(k):
+    """bts.py:167: `torch.abs(divided).min()` is NaN as soon as one denominator is NaN, and bts_main.py:484-486 logs
+    abs_min to hunt NaNs.  Both LPG entry points must report NaN (not the smallest finite |den|)."""
+    from bts_amd import ops
+    g = torch.Generator().manual_seed(k)
+    B, h, w = 2, 7, 12
+    plane = torch.rand((B, 4, h, w), generator=g) + 0.5
+    clean = plane.clone()
+    plane[1, 0, 3, 5] = float("nan")
+    for p, want_nan in ((clean, False), (plane, True)):
+        am = torch.empty((), device="cuda")
+        ops.lpg_forward(p.cuda(), k, abs_min=am)
+        ref_am = O.lpg_forward(p, k)[1]                      # the reference's own reduction (bts.py:167)
+        assert bool(torch.isnan(ref_am).item()) == want_nan
+        assert bool(torch.isnan(am).item()) == want_nan
+        if not want_nan:
+            assert am.item() == ref_am.item()               # the module-level op is bit-exact
+        p4 = p.permute(0, 2, 3, 1).reshape(-1, 4).contiguous().cuda()
+        out = torch.empty((B, 1, h * k, w * k), device="cuda")
+        am2 = torch.empty((), device="cuda")
+        ops.lpg_fused_forward(p4, B, h, w, k, 80.0, False, out, abs_min=am2)
+        assert bool(torch.isnan(am2).item()) == want_nan
+        if not want_nan:
+            assert am.item() > 0 and abs(am.item() - am2.item()) <= 1e-6 * am.item()
+    # the sub-batched model path reduces per-stream minima with torch.min, which propagates NaN as well
+    assert torch.isnan(torch.stack([torch.tensor(float("nan")), torch.tensor(1.0)]).min())
+
+
+# ------------------------------------------------------------------------------- graphs vs workspaces / weights
+def test_graphed_model_three_shapes_and_weight_change():
+    """(a) a third input shape must not evict workspaces a live graph replays into; (b) load_state_dict /
+    in-place weight changes after capture must re-capture, not replay stale packed weights."""
+    from bts_amd.graph import GraphedModel
+    m = _model("densenet121_bts").cuda()
+    m.sub_batches = 2
+    # make eviction pressure real: room for 2 unpinned workspaces only
+    m.decoder._bufs.max_entries = 2
+    gm = GraphedModel(m, max_shapes=4)
+    shapes = [(2, 64, 96), (2, 96, 64), (4, 64, 64)]
+    inputs = []
+    for i, (B, H, W) in enumerate(shapes):
+        inputs.append((t(synth.image_batch(B, H, W, 40 + i)).cuda(), t(synth.focal_values(B, "kitti", 40 + i)).cuda()))
+    with torch.no_grad():
+        eager = [[o.clone() for o in m(img, foc)] for img, foc in inputs]
+        for rnd in range(3):                       # round-robin: every graph is replayed after the others ran
+            for (img, foc), ref in zip(inputs, eager):
+                outs = gm(img, foc)
+                torch.cuda.synchronize()
+                for a, b in zip(outs, ref):
+                    assert torch.equal(a, b), "graph replay differs from eager (round %d)" % rnd
+        assert gm.captures == 3
+        for plan in m._enc_plans.values():
+            assert all(plan._ws.pinned(k) for k in plan._ws._entries)
+        assert sum(m.decoder._bufs.pinned(k) for k in m.decoder._bufs._entries) == 6      # 3 shapes x 2 sub-batches
+        # an eager forward on a 4th and 5th shape churns the unpinned part of the cache only
+        for B, H, W in ((1, 32, 64), (1, 64, 32)):
+            m(t(synth.image_batch(B, H, W, 1)).cuda(), t(synth.focal_values(B, "kitti", 1)).cuda())
+        for (img, foc), ref in zip(inputs, eager):
+            outs = gm(img, foc)
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(outs, ref))
+        # (b) new weights: same shapes, different results, and equal to a fresh eager forward
+        sd = copy.deepcopy(m.state_dict())
+        for k_, v in sd.items():
+            if v.is_floating_point() and v.dim() == 4:
+                v.mul_(1.03125)
+        m.load_state_dict(sd)
+        img, foc = inputs[0]
+        outs = [o.clone() for o in gm(img, foc)]
+        ref2 = m(img, foc)
+        torch.cuda.synchronize()
+        assert gm.captures == 4
+        assert all(torch.equal(a, b) for a, b in zip(outs, ref2))
+        assert not torch.equal(outs[4], eager[0][4])
+        # in-place optimiser-style update (bumps _version) -> re-capture again
+        for p in m.decoder.get_depth.parameters():
+            p.mul_(0.5)
+        outs = [o.clone() for o in gm(img, foc)]
+        assert gm.captures == 5 and all(torch.equal(a, b) for a, b in zip(outs, m(img, foc)))
+        # dropping graphs unpins their workspaces
+        gm2 = GraphedModel(m, max_shapes=1)
+        gm2(*inputs[0]); gm2(*inputs[1])
+        assert len(gm2._graphs) == 1
+
+
+def test_weight_change_after_forward_repacks():
+    """dist.broadcast_module copies into the parameters themselves (version bump) -- a rank that ran a
+    forward before the broadcast must compute with the broadcast weights afterwards."""
+    from bts_amd import dist as bdist, workspace
+    a, b = _model("densenet121_bts", seed=1).cuda(), _model("densenet121_bts", seed=2).cuda()
+    img = t(synth.image_batch(1, 64, 96, 7)).cuda()
+    foc = t(synth.focal_values(1, "kitti", 7)).cuda()
+    with torch.no_grad():
+        ra = [o.clone() for o in a(img, foc)]
+        rb0 = [o.clone() for o in b(img, foc)]              # b packs ITS weights
+        assert not torch.equal(ra[4], rb0[4])
+        for pb, pa in zip(list(b.parameters()) + list(b.buffers()), list(a.parameters()) + list(a.buffers())):
+            v0 = pb._version
+            pb.copy_(pa)                                    # what broadcast_module does on a receiving rank
+            assert pb._version > v0
+        rb1 = b(img, foc)
+        assert all(torch.equal(x, y) for x, y in zip(ra, rb1))
+        # writers that go through .data bump nothing: the documented escape hatch is invalidate_packs()
+        for pb in b.decoder.get_depth.parameters():
+            pb.data.mul_(2.0)
+        workspace.invalidate_packs()
+        rb2 = b(img, foc)
+        assert not torch.equal(rb2[4], rb1[4])
+    assert bdist.broadcast_module(a) is None                # not initialised: no-op
+
+
+def test_replicas_share_packs_and_workspaces():
+    """nn.DataParallel re-creates replicas with freshly broadcast parameters on every forward (bts_test.py:91): the
+    packed weights and workspaces must be found again (keyed on the SOURCE module's tensors), not rebuilt."""
+    from torch.nn.parallel import replicate
+    from bts_amd import ops
+    m = _model("densenet121_bts").cuda()
+    img = t(synth.image_batch(2, 64, 96, 7)).cuda()
+    foc = t(synth.focal_values(2, "kitti", 7)).cuda()
+    with torch.no_grad():
+        ref = [o.clone() for o in m(img, foc)]
+        calls = {"n": 0}
+        real = ops.pack_conv_weight
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return real(*a, **k)
+        ops.pack_conv_weight = counting
+        try:
+            try:
+                reps = replicate(m, [0, 0])
+            except Exception as e:                          # some torch builds refuse duplicate device ids
+                pytest.skip("replicate(model, [0, 0]) not supported here: %r" % (e,))
+            n_ws = len(m.decoder._bufs)
+            for r in reps:
+                assert r._origin[0] is m and r.decoder._packs.origin is m.decoder
+                outs = r(img, foc)
+                assert all(torch.equal(x, y) for x, y in zip(outs, ref))
+            assert calls["n"] == 0, "replicas re-packed %d conv weights" % calls["n"]
+            assert len(m.decoder._bufs) == n_ws
+        finally:
+            ops.pack_conv_weight = real
+
+
+def test_two_threads_two_streams_one_device():
+    """The library is re-entrant per (device, stream): two Python threads (DataParallel's execution model) launch the
+    128x128-tile convolution (73 728 B of dynamic LDS: needs the per-device attribute) on their own streams."""
+    from bts_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, h, w, cin, cout = 2, 24, 40, 256, 256
+    x = torch.randn((B * h * w, cin), generator=g).cuda()
+    wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.05).cuda()
+    wp, _, _ = ops.pack_conv_weight(wt)
+    ref = torch.empty((B * h * w, cout), device="cuda")
+    ops.conv_forward(x, B, h, w, wp, cout, 3, y2d=ref)
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                y = torch.empty((B * h * w, cout), device="cuda")
+                for _ in range(20):
+                    ops.conv_forward(x, B, h, w, wp, cout, 3, y2d=y)
+                st.synchronize()
+            results[i] = y
+        except Exception as e:                              # surfaced below: a thread must not die silently
+            errors.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t_.start() for t_ in th]
+    [t_.join() for t_ in th]
+    assert not errors, errors
+    assert torch.equal(results[0], ref) and torch.equal(results[1], ref)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
+def test_large_lds_tile_after_device_switch():
+    """conv_mfma.hip raises hipFuncAttributeMaxDynamicSharedMemorySize per DEVICE: the 128x128 tile must launch on
+    a second GPU of the same process, and nn.DataParallel over two devices must match the single-device forward."""
+    from bts_amd import ops
+    g = torch.Generator().manual_seed(6)
+    B, h, w, cin, cout = 1, 24, 40, 256, 256
+    x = torch.randn((B * h * w, cin), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * 0.05
+    outs = []
+    for dev in (0, 1, 0):
+        with torch.cuda.device(dev):
+            xd, wd = x.cuda(), wt.cuda()
+            wp, _, _ = ops.pack_conv_weight(wd)
+            y = torch.empty((B * h * w, cout), device="cuda")
+            ops.conv_forward(xd, B, h, w, wp, cout, 3, y2d=y)
+            torch.cuda.synchronize()
+            outs.append(y.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    m = _model("densenet121_bts").cuda()
+    img, foc = t(synth.image_batch(4, 64, 96, 7)).cuda(), t(synth.focal_values(4, "kitti", 7)).cuda()
+    with torch.no_grad():
+        ref = m(img, foc)
+        dp = torch.nn.DataParallel(m, device_ids=[0, 1])
+        for _ in range(2):
+            got = dp(img, foc)
+            assert all(torch.equal(a, b) for a, b in zip(got, ref))
+
+
+# ------------------------------------------------------------------------------------ unsupported configurations
+def test_unsupported_bts_size_fails_loudly():
+    """bts.py:198-217 derive every width from params.bts_size; libbts_hip.so builds the reduction chains and get_depth
+    of bts_size 512 only.  Anything else must raise BtsHipError(BTS_ERR_UNSUPPORTED), never compute
+    something else."""
+    from bts_amd import bts as M, ops
+    from bts_amd._lib import BtsHipError
+    feat = synth.ENCODER_CHANNELS["densenet121_bts"]
+    dec = M.bts(Params("densenet121_bts", 256, 80.0, "kitti"), feat, 256).eval().cuda()
+    feats, focal = make_inputs("K", 1, 32, 64, 1)
+    fe = synth.encoder_features(feat, 1, 32, 64, 1)
+    with torch.no_grad(), pytest.raises(BtsHipError, match="not built|UNSUPPORTED|unsupported"):
+        dec([None] + [t(f).cuda() for f in fe[1:]], focal.cuda())
+    x = torch.zeros((64, 48), device="cuda")
+    with pytest.raises(BtsHipError):
+        ops.reduc_forward_nhwc(x, 48, 24, torch.zeros(16, device="cuda"), 80.0, False, False, torch.empty((64, 4), device="cuda"))
+
+
+# --------------------------------------------------------------------------- full-size encoders (configs[1], [2])
+@pytest.mark.parametrize("enc,dataset,B,H,W", [("densenet161_bts", "kitti", 16, 352, 1216),
+                                               ("resnext101_bts", "nyu", 16, 416, 544)])
+def test_full_size_model_frame_independence_and_cpu_parity(enc, dataset, B, H, W):
+    """BASELINE configs[1]/[2] through the WHOLE model on HIP at full size: the B=16 launches take other tile /
+    split-K paths than the 64x96 tests.  (a) frame independence, bit-exact: frames 0 and B-1 of the batch-of-16
+    equal the batch-of-1 results; (b) frame 0 vs the torch-CPU encoder + CPU oracle decoder on the same weights."""
+    m = _model(enc, dataset).cuda()
+    m.sub_batches = 4
+    img = t(synth.image_batch(B, H, W, 1234))
+    foc = t(synth.focal_values(B, dataset, 1234))
+    with torch.no_grad():
+        full = [o.clone() for o in m(img.cuda(), foc.cuda())]
+        for i in (0, B - 1):
+            one = m(img[i:i + 1].cuda(), foc[i:i + 1].cuda())
+            for a, b in zip(one, full):
+                assert torch.equal(a[0], b[i]), "frame %d of the batch differs from the same frame alone" % i
+        m.sub_batches = 1                                     # and the single-stream launch of all 16 frames
+        single = m(img.cuda(), foc.cuda())
+        assert all(torch.equal(a, b) for a, b in zip(single, full))
+        # CPU reference for frame 0
+        cpu = copy.deepcopy(m).cpu()
+        feats = cpu.encoder(img[0:1])
+        state = {k: v for k, v in cpu.decoder.state_dict().items()}
+        md = 80.0 if dataset == "kitti" else 10.0
+        ref_outs, inter = O.decoder_forward(state, feats, foc[0:1], md, dataset, want_intermediates=True)
+    rep = check_outputs([o[0:1] for o in full], ref_outs, inter, rel_tol=1e-4, what="%s %dx%d frame 0" % (enc, H, W))
+    print(enc, {k: float("%.3g" % v) for k, v in rep.items()})
+
+
+# ------------------------------------------------------------------ configs[3]: the per-rank shard of B=64 / 8 GPUs
+def test_config3_rank_shard_b8_through_all_gather():
+    """BASELINE configs[3] is B=64 sharded over 8 GPUs = 8 frames of 352x1216 per rank.  One rank's workload end to end:
+    shard_range of the global batch, the b=8 forward, the packed all-gather of the five maps (world 1 here: the
+    collective itself is covered by the gloo tests), unshard -- equal to the frames run one by one."""
+    from bts_amd import dist as bdist
+    m = _model("densenet161_bts").cuda()
+    G, world, rank = 64, 8, 3
+    lo, hi = bdist.shard_range(G, rank, world)
+    assert (lo, hi) == (24, 32)
+    b = hi - lo
+    img = t(synth.image_batch(b, 352, 1216, 1234 + rank)).cuda()
+    foc = t(synth.focal_values(b, "kitti", 1234 + rank)).cuda()
+    with torch.no_grad():
+        outs = m(img, foc)
+        gathered, work = bdist.all_gather_depths(outs, 5)
+        assert work is None and tuple(gathered.shape) == (1, 5, b, 1, 352, 1216)
+        maps = bdist.unshard_depths(gathered)
+        for i in (0, 5, 7):
+            one = m(img[i:i + 1], foc[i:i + 1])
+            for j in range(5):
+                assert torch.equal(maps[j][i], one[j][0])
+        assert all(torch.isfinite(mm).all() for mm in maps[3:5])
+        assert tuple(outs[5].shape) == (b, 32, 352, 1216)          # iconv1 stays on the rank (not gathered)
+
+
+# ------------------------------------------------- configs[4]: the per-GPU training step (B=4, 352x704, DenseNet161)
+def test_config5_densenet161_train_step_b4_352x704_vs_cpu():
+    """BASELINE configs[4] per-GPU workload: one whole-model DenseNet161 training step (bts_main.py:476-500 protocol)
+    at B=4, 352x704 -- encoder + decoder on the HIP kernels -- against the same step on the CPU (torch encoder modules
+    + oracle decoder, autograd) in fp32: loss, final depth, and the gradient (global relative L2 + per-tensor bars)."""
+    from bts_amd import bts as M
+    params = Params("densenet161_bts", 512, 80.0, "kitti")
+    torch.manual_seed(21)
+    model = M.BtsModel(params).train()
+    B, H, W = 4, 352, 704
+    x = torch.from_numpy(synth.image_batch(B, H, W, 5))
+    focal = torch.from_numpy(synth.focal_values(B, "kitti", 5))
+    gt, mask = synth.train_targets(B, H, W, 80.0, 9)
+    enc = copy.deepcopy(model.encoder)
+    state = {k: (v.detach().clone() if v.is_floating_point() else v.clone()) for k, v in model.decoder.state_dict().items()}
+    for k, v in state.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    outs_ref = O.decoder_forward(state, enc(x), focal, 80.0, "kitti", training=True)
+    loss_ref = O.silog_loss(outs_ref[4], t(gt), t(mask), 0.85)
+    loss_ref.backward()
+    ref = {"encoder." + n: p.grad.numpy() for n, p in enc.named_parameters()}
+    ref.update({"decoder." + n: v.grad.numpy() for n, v in state.items() if v.requires_grad})
+    mg = model.cuda()
+    outs = mg(x.cuda(), focal.cuda())
+    loss = M.silog_loss(0.85)(outs[4], t(gt).cuda(), t(mask).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) <= 2e-4 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    fd, fr = outs[4].detach().cpu(), outs_ref[4].detach()
+    assert ((fd - fr).abs() / fr.abs().clamp_min(1e-3)).max().item() <= 1e-3
+    got = {n: p.grad.cpu().numpy() for n, p in mg.named_parameters()}
+    per, l2 = grad_error_report(got, ref)
+    errs = sorted(per.values())
+    print("DenseNet161 B=4 352x704 step vs CPU fp32: loss %.6f / %.6f, global rel-L2 %.2e, worst tensor %.2e, 90th pct %.2e"
+          % (loss.item(), loss_ref.item(), l2, errs[-1], errs[int(0.9 * (len(errs) - 1))]))
+    assert len(per) > 600
+    assert_grads_close(per, l2, "densenet161 B=4 352x704 / cpu fp32", typical=1e-2, worst=0.1, l2=5e-3, worst_large=5e-2)
