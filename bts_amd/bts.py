@@ -508,6 +508,9 @@ class encoder(nn.Module):
         return taps
 
 
+_SIDE_STREAMS: Dict[str, list] = {}
+
+
 class BtsModel(nn.Module):
     """bts.py:341-349.  Same constructor and forward signature.
 
@@ -525,7 +528,6 @@ class BtsModel(nn.Module):
                                             # (MI355X, B=16: 1 -> 54.7, 2 -> 48.4, 4 -> 47.6, 8 -> 51.5 ms/step)
         self._origin = [self]               # reaches DataParallel replicas through replicate()'s shallow __dict__ copy
         self._enc_plans = {}                # device -> DenseNetHip / ResNetHip (packs + workspaces), shared with replicas
-        self._side_streams = {}
 
     def _native_ok(self, x):
         return (self.native_encoder and not self.training and isinstance(x, torch.Tensor) and x.is_cuda
@@ -542,6 +544,7 @@ class BtsModel(nn.Module):
             plan._src = src_base
             self._enc_plans[str(x.device)] = plan
         plan.bind(base, key_module=src_base)
+        plan._ws.max_entries = max(plan._ws.max_entries, 2 * int(self.sub_batches))
         B, _, H, W = x.shape
         dec = self.decoder
         ws = dec._workspace(B, H, W, x.device, slot)
@@ -571,9 +574,11 @@ class BtsModel(nn.Module):
         dev = x.device
         nf16 = self.decoder.num_features // 16
         full = [torch.empty((B, c, H, W), dtype=torch.float32, device=dev) for c in (1, 1, 1, 1, 1, nf16)]
-        streams = self._side_streams.setdefault(str(dev), [])
-        while len(streams) < S:
+        streams = _SIDE_STREAMS.setdefault(str(dev), [])        # per device, process-wide (not module state: a module
+        while len(streams) < S:                                  # holding Stream objects cannot be deep-copied / saved)
             streams.append(torch.cuda.Stream(dev))
+        dec_ws = self.decoder._bufs                              # one forward needs S workspaces alive at once
+        dec_ws.max_entries = max(dec_ws.max_entries, 2 * S)
         cur = torch.cuda.current_stream(dev)
         b = B // S
         mins = []

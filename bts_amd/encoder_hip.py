@@ -57,6 +57,9 @@ class DenseNetHip:
         self.c_in = [b.num_input_features for b in self.blocks]
         self.c_out = [b.num_input_features + len(b) * b.growth_rate for b in self.blocks]
 
+    def __reduce__(self):          # deepcopy / pickle of the owning model: a fresh plan (no packs, no workspaces)
+        return (DenseNetHip, (self.features, self.key_module))
+
     def bind(self, features: nn.Sequential, key_module: Optional[nn.Module] = None):
         """Point the plan at another instance of the same network -- a DataParallel replica, re-created on every
         forward (bts_test.py:91) -- without dropping packs or workspaces: the packs are fingerprinted on
@@ -199,6 +202,9 @@ class ResNetHip:
         self.c_stem = model.conv1.out_channels
         self.c_out = [l[-1].conv3.out_channels for l in self.layers]
         self.width = [l[0].conv2.out_channels for l in self.layers]
+
+    def __reduce__(self):
+        return (ResNetHip, (self.model, self.key_module))
 
     def bind(self, model: nn.Module, key_module: Optional[nn.Module] = None):
         """See DenseNetHip.bind."""

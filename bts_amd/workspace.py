@@ -4,9 +4,9 @@ Two host-side mechanisms the fused forward depends on:
 
 ``WorkspaceCache`` -- the NHWC buffers of one (batch, height, width, device, sub-batch slot).  libbts_hip.so never
 allocates, so a forward's launches carry raw pointers into these buffers, and a captured hipGraph keeps replaying
-those pointers.  Eviction is therefore LRU over UNPINNED entries only: ``graph.GraphedModel`` records which entries a
-capture touched (``recording()``) and pins them for as long as the graph lives.  A cache that is full of pinned
-entries grows instead of handing memory that a live graph still writes to back to the allocator.
+those pointers.  Eviction is therefore LRU over UNPINNED entries only (``max_entries`` of them are kept):
+``graph.GraphedModel`` records which entries a capture touched (``recording()``) and pins them for as long as the graph
+lives; pinned entries never count against the limit and are never handed back to the allocator under a live graph.
 
 ``PackCache`` -- kernel-layout copies of a module's weights (packed conv weights, folded BN vectors), rebuilt when
 the parameters change (``load_state_dict``, an optimiser step, ``.cuda()``: detected through ``data_ptr``/``_version``).
@@ -47,6 +47,11 @@ class WorkspaceCache:
         self._pins: Dict[Hashable, int] = {}
         self._lock = threading.Lock()
 
+    def __reduce__(self):
+        # copy.deepcopy(model) / torch.save(model): a copy starts with an EMPTY cache (buffers are scratch, and a lock
+        # cannot be copied)
+        return (WorkspaceCache, (self.max_entries,))
+
     def __len__(self):
         return len(self._entries)
 
@@ -70,13 +75,16 @@ class WorkspaceCache:
         return ws
 
     def _evict(self, keep):
-        if len(self._entries) <= self.max_entries:
-            return
-        for k in list(self._entries.keys()):               # oldest first
-            if len(self._entries) <= self.max_entries:
+        # the limit counts UNPINNED entries: pinned ones (live graphs) are extra, so a forward that needs S slots keeps
+        # all S of them whatever the graphs hold
+        free = [k for k in self._entries if self._pins.get(k, 0) == 0]      # oldest first
+        excess = len(free) - self.max_entries
+        for k in free:
+            if excess <= 0:
                 break
-            if k != keep and self._pins.get(k, 0) == 0:
+            if k != keep:
                 del self._entries[k]
+                excess -= 1
 
     def pin(self, key):
         with self._lock:
@@ -117,6 +125,10 @@ class PackCache:
     def __init__(self, owner: nn.Module):
         self._origin = [owner]             # a list, so nn.Module.__setattr__ does not register it as a sub-module
         self._entries: Dict[str, Tuple] = {}
+
+    def __reduce__(self):
+        # deepcopy / pickle: the copy's cache is empty and its origin is the COPIED owner (the memo resolves the cycle)
+        return (PackCache, (self._origin[0],))
 
     @property
     def origin(self) -> nn.Module:

@@ -148,3 +148,41 @@ def test_trainer_protocol_pieces():
     gt = torch.tensor([0.05, 0.5, 1.5])
     assert trainer.gt_mask(gt, "kitti").tolist() == [False, False, True]
     assert trainer.gt_mask(gt, "nyu").tolist() == [False, True, True]
+
+
+def test_caches_survive_deepcopy_pickle_and_replication():
+    """The packed-weight / workspace caches (bts_amd/workspace.py) must not break what callers do with the model
+    object: copy.deepcopy (tests, EMA copies), torch.save(model) (a lock is not picklable), and DataParallel's
+    replicate(), whose shallow __dict__ copy is how replicas find the SOURCE module's caches (bts_test.py:91)."""
+    import copy
+    import io
+    from types import SimpleNamespace
+    from bts_amd import bts as M
+    from bts_amd.encoder_hip import DenseNetHip
+    from bts_amd.workspace import WorkspaceCache
+    m = M.BtsModel(SimpleNamespace(encoder="densenet121_bts", bts_size=512, max_depth=80.0, dataset="kitti"))
+    m._enc_plans["cuda:0"] = DenseNetHip(m.encoder.base_model, key_module=m.encoder.base_model)
+    c = copy.deepcopy(m)
+    assert c._origin[0] is c and c.decoder._packs.origin is c.decoder and c.decoder._bufs is not m.decoder._bufs
+    assert c._enc_plans["cuda:0"].features is c.encoder.base_model
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)            # a file this test wrote itself
+    assert r._origin[0] is r and r.decoder.daspp_6._packs.origin is r.decoder.daspp_6
+    rep = m.decoder._replicate_for_data_parallel()
+    assert rep._packs is m.decoder._packs and rep._bufs is m.decoder._bufs and rep._packs.origin is m.decoder
+    # LRU eviction over UNPINNED entries only: pinned ones (live graphs) are extra and never dropped
+    wc = WorkspaceCache(max_entries=2)
+    for k in "abc":
+        wc.get(k, dict)
+        wc.pin(k)
+    wc.get("d", dict)
+    wc.get("e", dict)
+    assert len(wc) == 5 and all(k in wc for k in "abcde")        # 3 pinned + 2 unpinned
+    wc.get("f", dict)
+    assert "d" not in wc and all(k in wc for k in "abcef")      # oldest unpinned one went
+    wc.unpin("a")
+    assert "a" not in wc and len(wc) == 4                        # unpinned and least recently used: a goes, e and f stay
+    wc.get("g", dict)
+    assert all(k in wc for k in "bcfg") and len(wc) == 4

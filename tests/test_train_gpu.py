@@ -394,7 +394,9 @@ def test_decoder_train_step_full_training_crop_vs_oracle():
           % (l2, max(per.values()), sorted(per.values())[int(0.9 * (len(per) - 1))]))
     # fp32 against fp32 (both sides carry their own rounding / ReLU-mask flips; per-tensor maxima over up to 10 M
     # elements): per-tensor bars are loose, the global relative L2 -- measured 3.3e-4 -- is the tight one
-    assert_grads_close(per, l2, "352x704 decoder step", typical=1e-2, worst=0.1, l2=2e-3)
+    # both sides are fp32 here (two independent noise sources), so large tensors get 3e-2 where a comparison against
+    # fp64 gets 2e-2 (measured worst large tensor: 2.0e-2, daspp_6's 1x1 weight)
+    assert_grads_close(per, l2, "352x704 decoder step", typical=1e-2, worst=0.1, l2=2e-3, worst_large=3e-2)
 
 
 def test_btsmodel_train_step_resnext50_vs_cpu():
