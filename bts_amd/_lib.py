@@ -16,10 +16,10 @@ SYMBOLS = (
     "bts_reduc_fwd_f32", "bts_conv_fwd_f32", "bts_nchw_to_nhwc_f32", "bts_nhwc_to_nchw_f32",
     "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32", "bts_maxpool3x3s2_nhwc_f32", "bts_bn_relu_avgpool2_nhwc_f32",
     "bts_conv_wgrad_f32", "bts_bn_train_ws_floats", "bts_bn_train_stats_f32", "bts_bn_apply_nhwc_f32", "bts_bn_train_bwd_f32",
-    "bts_pack_weights_blocks", "bts_pack_weights_f32",
+    "bts_pack_weights_blocks", "bts_pack_weights_f32", "bts_eval_ws_doubles", "bts_eval_depth_metrics_f32",
 )
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ConvDesc(C.Structure):
@@ -129,6 +129,10 @@ def load():
     lib.bts_pack_planes_f32.argtypes = [vp, vp, vp, vp, i, l, vp, l, vp]
     lib.bts_get_depth_f32.restype = i
     lib.bts_get_depth_f32.argtypes = [vp, vp, i, i, i, i, f, vp, vp, vp]
+    lib.bts_eval_ws_doubles.restype = l
+    lib.bts_eval_ws_doubles.argtypes = [i, i, i]
+    lib.bts_eval_depth_metrics_f32.restype = i
+    lib.bts_eval_depth_metrics_f32.argtypes = [vp, i, i, i, vp, i, i, i, i, f, f, i, i, i, i, vp, l, vp, vp, vp]
     if lib.bts_hip_abi_version() != ABI_VERSION:
         raise BtsHipError("bts_amd: ABI version mismatch (%d != %d)" % (lib.bts_hip_abi_version(), ABI_VERSION))
     _lib = lib

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 4
+#define BTS_HIP_ABI_VERSION 5
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -276,6 +276,31 @@ int bts_bn_relu_avgpool2_nhwc_f32(const float* src, long src_pix_stride, int B, 
  */
 int bts_get_depth_f32(const float* iconv1, const float* w, int B, int C, int H, int W, float max_depth,
                       const float* focal, float* final_depth, bts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Evaluation metrics as GPU reductions.  Replaces the per-sample body of online_eval +
+ * compute_errors (pytorch/bts_main.py:87-108, 221-254; same code in bts_eval.py:81-102, 237-307), which copies both
+ * maps to the host and runs ~25 NumPy passes per sample.
+ *
+ *   pred  : [B,Hp,Wp] network output (metres).  With do_kb_crop the prediction is pasted into a zero canvas of the
+ *           ground truth's size at (top,left) = (Hg-352, (Wg-1216)/2) (bts_main.py:221-227); otherwise Hp==Hg,
+ *           Wp==Wg, top=left=0.
+ *   gt    : [B,Hg,Wg] ground-truth depth.
+ *   clamp : pred<min -> min, pred>max -> max, +inf -> max, NaN -> min (bts_main.py:229-232)
+ *   valid : min < gt < max (bts_main.py:234) AND y in [y0,y1), x in [x0,x1) -- the Garg / Eigen crop rectangle of
+ *           bts_main.py:236-249 in ground-truth coordinates (0,Hg,0,Wg = no crop)
+ *   per_frame : [B][10] doubles <- silog, abs_rel, log10, rms, sq_rel, log_rms, d1, d2, d3 (bts_main.py:84 order),
+ *           then the number of valid pixels.
+ *   accum : optional [10] doubles, the running `eval_measures` of online_eval: += the nine measures and [9] += 1 for
+ *           every frame that has valid pixels (bts_main.py:253-254); all-reduced by the caller (bts_main.py:258-260).
+ *   ws    : scratch of bts_eval_ws_doubles(B,Hg,Wg) doubles.
+ * Sums are fp64 in a fixed order (no atomics): bit-reproducible; the reference reduces in float32.
+ */
+long bts_eval_ws_doubles(int B, int Hg, int Wg);
+int bts_eval_depth_metrics_f32(const float* pred, int B, int Hp, int Wp, const float* gt, int Hg, int Wg,
+                               int top, int left, float min_depth_eval, float max_depth_eval,
+                               int y0, int y1, int x0, int x1, double* ws, long ws_doubles,
+                               double* per_frame, double* accum, bts_stream_t stream);
 
 #ifdef __cplusplus
 }
