@@ -38,6 +38,7 @@ struct ConvKnobs {
     int no48, force_bm;                                    // BTS_CONV_NO48, BTS_CONV_BM
     int precision, emu_sb;                                 // BTS_CONV_PRECISION, BTS_CONV_EMU_SB (-1 = unset)
     int w8, w8s;                                           // BTS_CONV_W8, BTS_CONV_W8S
+    int halo;                                              // BTS_CONV_HALO: 1 = halo-tile kernel where eligible (default), 0 = off
 };
 inline long env_long(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
 const ConvKnobs& knobs() {
@@ -45,7 +46,8 @@ const ConvKnobs& knobs() {
                                 env_long("BTS_CONV_SPLITK_TARGET", 1024), env_long("BTS_CONV_LDS_KB", 0) * 1024,
                                 (int)env_long("BTS_CONV_NO48", 0), (int)env_long("BTS_CONV_BM", 0),
                                 (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
-                                (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1)};
+                                (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1),
+                                (int)env_long("BTS_CONV_HALO", 1)};
     return k;
 }
 // floats per LDS row (32 + pad), chosen per MFMA shape so that the 16 rows a ds_read_b128 lane group touches
@@ -565,6 +567,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
         }
 }
 
+#include "conv_halo.inc"
+
 // Second pass of a split-K convolution: out = E(sum_s ws[s][m][n]) in a FIXED order (deterministic), then the
 // same epilogue / destinations as the fused path.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, int nchw) {
@@ -589,6 +593,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, in
     }
 }
 
+// Split K over several workgroups when the grid would leave most of the 256 CUs idle (M-starved deep encoder layers)
+// and the caller lent a workspace.  The decision is a function of the PER-FRAME geometry only (H*W, c_out) -- sized
+// for the nominal 8-frame sub-batch -- never of the batch size: an output element's summation order, hence its bits,
+// must not depend on how many frames share the launch (frames are independent, bts.py:223-293).
+inline bool wants_split(const ConvArgs& a) {
+    if (a.n_classes != 1 || a.ws == nullptr || knobs().split_max <= 1) return false;
+    const long tiles64 = ((8L * a.H * a.W + 63) / 64) * a.n_ntiles;
+    return tiles64 < knobs().split_below;
+}
+
 template <int BM, int BN, int WM, int WN, int MF = 32, int PREC = 0>
 int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     ConvArgs a = a0;
@@ -603,18 +617,14 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     const int nit_all = a.k_pad / BK;
     a.ksplit = 1; a.its_per_split = nit_all; a.ws_ld = (a.c_out + 3) & ~3;
     const int split_max = knobs().split_max;
-    const long split_below = knobs().split_below;
-    if (a.n_classes == 1 && a.ws != nullptr && split_max > 1) {
+    if (wants_split(a)) {
         const long tiles64 = ((8L * a.H * a.W + 63) / 64) * a.n_ntiles;     // 64-row tiles of a nominal 8-frame launch
-        if (tiles64 < split_below) {
-            const long split_target = knobs().split_target;
-            long sp = split_target / tiles64;
-            if (sp > split_max) sp = split_max;
-            if (sp > nit_all / 4) sp = nit_all / 4;
-            if (sp > 1 && sp * a.M * a.ws_ld <= ws_floats) {
-                a.its_per_split = (nit_all + (int)sp - 1) / (int)sp;
-                a.ksplit = (nit_all + a.its_per_split - 1) / a.its_per_split;     // no empty splits
-            }
+        long sp = knobs().split_target / tiles64;
+        if (sp > split_max) sp = split_max;
+        if (sp > nit_all / 4) sp = nit_all / 4;
+        if (sp > 1 && sp * a.M * a.ws_ld <= ws_floats) {
+            a.its_per_split = (nit_all + (int)sp - 1) / (int)sp;
+            a.ksplit = (nit_all + a.its_per_split - 1) / a.its_per_split;     // no empty splits
         }
     }
     const long nwg = tiles * a.ksplit;
@@ -762,6 +772,24 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
         if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4, 32, 1>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 4, 32, 1>(a, nchw, s, wsf);
         if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2, 32, 1>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2, 32, 1>(a, nchw, s, wsf);
         return launch_conv<128, 32, 4, 1, 32, 1>(a, nchw, s, wsf);
+    }
+    // stride-1 3x3 (and sub-pixel 2x2) convolutions on maps that tile well: the halo-tile kernel (conv_halo.inc).  The
+    // choice depends on per-frame geometry only (never on B), like the split-K decision.
+    if (knobs().halo) {
+        ConvArgs probe = a;
+        probe.n_ntiles = (a.c_out + bn - 1) / bn;
+        if (!wants_split(probe) && halo_eligible(a, true, bn == 48 ? 16 : 32, nullptr)) {
+            if (a.subpix) {
+                if (bn == 128) return launch_halo<128, 4, 2, 32, 2>(a, nchw, s);
+                if (bn == 64) return launch_halo<64, 4, 2, 32, 2>(a, nchw, s);
+                if (bn == 32) return launch_halo<32, 4, 1, 32, 2>(a, nchw, s);
+            } else {
+                if (bn == 128) return launch_halo<128, 4, 2, 32, 3>(a, nchw, s);
+                if (bn == 64) return launch_halo<64, 4, 2, 32, 3>(a, nchw, s);
+                if (bn == 32) return launch_halo<32, 4, 1, 32, 3>(a, nchw, s);
+                if (bn == 48) return launch_halo<48, 8, 1, 16, 3>(a, nchw, s);
+            }
+        }
     }
     if (bn == 48) return bm == 128 ? launch_conv<128, 48, 4, 1, 16>(a, nchw, s, wsf) : launch_conv<64, 48, 4, 1, 16>(a, nchw, s, wsf);
     // 8-wave workgroups (two waves per SIMD from the same tile) for the 128-row tiles: +2 % end to end over the

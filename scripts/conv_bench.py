@@ -24,22 +24,36 @@ def layers(B, H=352, W=1216):
     return L
 
 
+def enc_layers(B, H=352, W=1216):
+    """DenseNet161 dense layers (first / middle / last of each block) and transitions: (name, (h,w), cin, cout, k, dil, up)."""
+    L = []
+    for bi, (s, c0, n) in enumerate(((4, 96, 6), (8, 192, 12), (16, 384, 36), (32, 1056, 24))):
+        h, w = H // s, W // s
+        for li in sorted({0, n // 2, n - 1}):
+            cin = c0 + 48 * li
+            L += [("b%d.l%d.1x1" % (bi + 1, li), (h, w), cin, 192, 1, 1, 1), ("b%d.l%d.3x3" % (bi + 1, li), (h, w), 192, 48, 3, 1, 1)]
+    return L
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--set", default="dec", choices=["dec", "enc", "all"])
     a = ap.parse_args()
     B = a.batch
     tot_ms = tot_fl = 0.0
-    for name, (h, w), cin, cout, k, dil, up in layers(B):
+    todo = (layers(B) if a.set in ("dec", "all") else []) + (enc_layers(B) if a.set in ("enc", "all") else [])
+    for name, (h, w), cin, cout, k, dil, up in todo:
         if a.only and a.only not in name:
             continue
         x = torch.randn(B * h * w, cin, device="cuda")
         wt = torch.randn(cout, cin, k, k, device="cuda") * 0.05
-        wp, cop, kp = ops.pack_conv_weight(wt)
+        sub = up == 2 and k == 3
+        wp, cop, kp = ops.pack_upconv_subpixel(wt) if sub else ops.pack_conv_weight(wt)
         y = torch.empty(B * h * up * w * up, cout, device="cuda")
-        run = lambda: ops.conv_forward(x, B, h, w, wp, cout, k, dil=dil, up=up, act=ops.ACT_ELU, y2d=y)
+        run = lambda: ops.conv_forward(x, B, h, w, wp, cout, k, dil=dil, up=up, act=ops.ACT_ELU, y2d=y, subpixel=sub)
         run()
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,7 +62,7 @@ def main():
             s.record(); run(); e.record(); torch.cuda.synchronize()
             best = min(best, s.elapsed_time(e))
         M = B * h * up * w * up
-        fl = 2.0 * M * cout * cin * k * k
+        fl = 2.0 * M * cout * cin * (4 if sub else k * k)       # EXECUTED flops (sub-pixel upconv: 4 taps per output)
         tot_ms += best
         tot_fl += fl
         print("%-11s M=%8d K=%6d N=%4d  %8.1f us  %6.1f TF" % (name, M, cin * k * k, cout, best * 1e3, fl / best / 1e9), flush=True)
