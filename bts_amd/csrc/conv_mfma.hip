@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -38,7 +39,7 @@ struct ConvKnobs {
     int no48, force_bm;                                    // BTS_CONV_NO48, BTS_CONV_BM
     int precision, emu_sb;                                 // BTS_CONV_PRECISION, BTS_CONV_EMU_SB (-1 = unset)
     int w8, w8s;                                           // BTS_CONV_W8, BTS_CONV_W8S
-    int halo;                                              // BTS_CONV_HALO: 1 = halo-tile kernel where eligible (default), 0 = off
+    int halo;                                              // BTS_CONV_HALO: 0 off, 1 = halo-tile kernel where eligible unless split-K applies, 2 = also instead of split-K (default)
 };
 inline long env_long(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
 const ConvKnobs& knobs() {
@@ -47,7 +48,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_NO48", 0), (int)env_long("BTS_CONV_BM", 0),
                                 (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
                                 (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1),
-                                (int)env_long("BTS_CONV_HALO", 1)};
+                                (int)env_long("BTS_CONV_HALO", 2)};
     return k;
 }
 // floats per LDS row (32 + pad), chosen per MFMA shape so that the 16 rows a ds_read_b128 lane group touches
@@ -778,7 +779,7 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if (knobs().halo) {
         ConvArgs probe = a;
         probe.n_ntiles = (a.c_out + bn - 1) / bn;
-        if (!wants_split(probe) && halo_eligible(a, true, bn == 48 ? 16 : 32, nullptr)) {
+        if ((knobs().halo >= 2 || !wants_split(probe)) && halo_eligible(a, true, bn == 48 ? 16 : 32, nullptr)) {
             if (a.subpix) {
                 if (bn == 128) return launch_halo<128, 4, 2, 32, 2>(a, nchw, s);
                 if (bn == 64) return launch_halo<64, 4, 2, 32, 2>(a, nchw, s);
@@ -787,7 +788,7 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
                 if (bn == 128) return launch_halo<128, 4, 2, 32, 3>(a, nchw, s);
                 if (bn == 64) return launch_halo<64, 4, 2, 32, 3>(a, nchw, s);
                 if (bn == 32) return launch_halo<32, 4, 1, 32, 3>(a, nchw, s);
-                if (bn == 48) return launch_halo<48, 8, 1, 16, 3>(a, nchw, s);
+                if (bn == 48) return launch_halo<48, 4, 1, 16, 3>(a, nchw, s);
             }
         }
     }
