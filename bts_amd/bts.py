@@ -301,9 +301,17 @@ class bts(nn.Module):
         n_d = 5 * (nf // 4)
         perm = torch.cat([torch.arange(nf // 2, nf // 2 + n_d), torch.arange(0, nf // 2)])
         P["daspp_conv"] = ops.pack_conv_weight(self.daspp_conv[0].weight.detach(), perm=perm)
-        P["conv3"] = ops.pack_conv_weight(self.conv3[0].weight.detach())
-        P["conv2"] = ops.pack_conv_weight(self.conv2[0].weight.detach())
-        P["conv1"] = ops.pack_conv_weight(self.conv1[0].weight.detach())
+        # conv3 / conv2 / conv1 read their last 1 / 1 / 4 input channels (depth_8x8_scaled_ds, depth_4x4_scaled_ds;
+        # reduc1x1 + the three depth maps: bts.py:260, 274, 287) from dense planes -- bts_conv_desc.tail_planes -- so
+        # the packed K axis is [buffer channels | 4 tail slots]
+        for name, m in (("conv3", self.conv3), ("conv2", self.conv2), ("conv1", self.conv1)):
+            w = m[0].weight.detach()
+            n_tail = 4 if name == "conv1" else 1
+            c_main = w.shape[1] - n_tail
+            if c_main % 4:
+                raise BtsHipError("bts: %s has %d feature channels in front of its depth planes; the planar-tail "
+                                  "convolution needs a multiple of 4" % (name, c_main))
+            P[name] = ops.pack_conv_weight(w, c_in_ld=c_main + 4)
         P["bn5"] = _bn_vecs(self.bn5, ops.round_up(nf, 32))
         P["bn4"] = _bn_vecs(self.bn4, ops.round_up(nf // 2, 32))
         P["bn4_2"] = _bn_vecs(self.bn4_2, ops.round_up(nf // 2, 32))
@@ -333,13 +341,15 @@ class bts(nn.Module):
             mid=z(n8, nf // 2),
             daspp_feat=z(n8, nf // 4),
             plane8=z(n8, 4),
-            cat3=z(n4, r4(nf // 4 + f[1] + 1, 4)),               # [upconv3 | skip1 | depth_8x8_scaled_ds | 0-pad]
+            cat3=z(n4, nf // 4 + f[1]),                          # [upconv3 | skip1]; depth_8x8_scaled_ds is the plane ds8
+            ds8=torch.zeros(n4, dtype=torch.float32, device=device),
             iconv3=z(n4, nf // 4),
             plane4=z(n4, 4),
-            cat2=z(n2, r4(nf // 8 + f[0] + 1, 4)),               # [upconv2 | skip0 | depth_4x4_scaled_ds | 0-pad]
+            cat2=z(n2, nf // 8 + f[0]),                          # [upconv2 | skip0]; depth_4x4_scaled_ds is the plane ds4
+            ds4=torch.zeros(n2, dtype=torch.float32, device=device),
             iconv2=z(n2, nf // 8),
             plane2=z(n2, 4),
-            cat1=z(n1, nf // 16 + 4),                            # [upconv1 | reduc1x1 d2 d4 d8]
+            cat1=z(n1, nf // 16),                                # upconv1; reduc1x1 / d2 / d4 / d8 are read as planes
             # scratch for split-K of under-filled launches (bts_conv_desc.splitk_ws): 8 splits x [n16, nf]
             splitk=torch.empty(8 * n16 * nf, dtype=torch.float32, device=device),
         )
@@ -395,11 +405,11 @@ class bts(nn.Module):
         ELU = ops.ACT_ELU
 
         def conv(name_w, x2d, hh, ww, cout, y2d=None, y_nchw=None, up=1, e2=None, c_in_real=None, pre=None,
-                 pre_relu=False):
+                 pre_relu=False, tail=None):
             wp = P[name_w] if isinstance(name_w, str) else name_w
             return ops.conv_forward(x2d, B, hh, ww, wp[0], cout, 3, dil=1, up=up, act=ELU, e2=e2, pre=pre, pre_relu=pre_relu,
                                     y2d=y2d, y_nchw=y_nchw, tag="decoder_upconv" if up == 2 else "decoder_conv",
-                                    c_in_real=c_in_real, subpixel=(up == 2), splitk_ws=ws["splitk"])
+                                    c_in_real=c_in_real, subpixel=(up == 2), splitk_ws=ws["splitk"], tail_planes=tail)
 
         # H/16 and H/8 trunk (bts.py:226-235)
         conv(self.upconv5.packed(), dense2d, H // 32, W // 32, nf, y2d=ws["cat5"][:, :nf], up=2, e2=P["bn5"],
@@ -438,23 +448,23 @@ class bts(nn.Module):
         a8 = am()
         c3 = ws["cat3"]
         ops.lpg_fused_forward(ws["plane8"], B, h8, w8, 8, md, False, depth_8x8_scaled,
-                              ds_out=c3[:, q + f[1]], ds_factor=4, ds_pix_stride=c3.stride(0), abs_min=a8)
+                              ds_out=ws["ds8"], ds_factor=4, ds_pix_stride=1, abs_min=a8)        # dense plane
         self.lpg8x8.abs_min = a8
 
         # H/4 (bts.py:258-270)
         conv(self.upconv3.packed(), ws["daspp_feat"], h8, w8, q, y2d=c3[:, :q], up=2, e2=P["bn3"])
-        conv("conv3", c3, h4, w4, q, y2d=ws["iconv3"], c_in_real=q + f[1] + 1)
+        conv("conv3", c3, h4, w4, q, y2d=ws["iconv3"], c_in_real=q + f[1] + 1, tail=[ws["ds8"]])
         self.reduc4x4.run_nhwc(ws["iconv3"], ws["plane4"], True)
         depth_4x4_scaled = out_tensor(1, 1)
         a4 = am()
         c2 = ws["cat2"]
         ops.lpg_fused_forward(ws["plane4"], B, h4, w4, 4, md, False, depth_4x4_scaled,
-                              ds_out=c2[:, nf // 8 + f[0]], ds_factor=2, ds_pix_stride=c2.stride(0), abs_min=a4)
+                              ds_out=ws["ds4"], ds_factor=2, ds_pix_stride=1, abs_min=a4)
         self.lpg4x4.abs_min = a4
 
         # H/2 (bts.py:272-283)
         conv(self.upconv2.packed(), ws["iconv3"], h4, w4, nf // 8, y2d=c2[:, :nf // 8], up=2, e2=P["bn2"])
-        conv("conv2", c2, h2, w2, nf // 8, y2d=ws["iconv2"], c_in_real=nf // 8 + f[0] + 1)
+        conv("conv2", c2, h2, w2, nf // 8, y2d=ws["iconv2"], c_in_real=nf // 8 + f[0] + 1, tail=[ws["ds4"]])
         self.reduc2x2.run_nhwc(ws["iconv2"], ws["plane2"], True)
         depth_2x2_scaled = out_tensor(2, 1)
         a2 = am()
@@ -464,12 +474,13 @@ class bts(nn.Module):
         # full resolution (bts.py:285-291)
         c1 = ws["cat1"]
         n16c = nf // 16
-        conv(self.upconv1.packed(), ws["iconv2"], h2, w2, n16c, y2d=c1[:, :n16c], up=2)
+        conv(self.upconv1.packed(), ws["iconv2"], h2, w2, n16c, y2d=c1, up=2)
         reduc1x1 = out_tensor(3, 1)
-        self.reduc1x1.run_nhwc(c1[:, :n16c], reduc1x1, False)
-        ops.pack_planes([reduc1x1, depth_2x2_scaled, depth_4x4_scaled, depth_8x8_scaled], c1[:, n16c:n16c + 4])
+        self.reduc1x1.run_nhwc(c1, reduc1x1, False)
         iconv1 = out_tensor(5, n16c)
-        conv("conv1", c1, H, W, n16c, y_nchw=iconv1)
+        # concat1 = cat[upconv1, reduc1x1, depth_2x2, depth_4x4, depth_8x8] (bts.py:287): the four maps are read in place
+        conv("conv1", c1, H, W, n16c, y_nchw=iconv1, c_in_real=n16c + 4,
+             tail=[reduc1x1, depth_2x2_scaled, depth_4x4_scaled, depth_8x8_scaled])
         fo = None
         if self.params.dataset == 'kitti':
             fo = focal.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()

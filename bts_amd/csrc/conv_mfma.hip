@@ -83,6 +83,8 @@ struct ConvArgs {
     // slice of the epilogue / prologue vectors.  bundled == 0: plain (n_classes 1) or sub-pixel (n_classes 4).
     int n_classes, bundled;
     const float* res; long res_pix_stride;   // optional residual added after e1, before the activation (NHWC)
+    const float* tail[4];                    // planar tail operand (conv_halo.inc); tail[j] = plane 0 for unused slots
+    int n_tail;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -696,7 +698,7 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     if (d->c_in_ld <= 0 || (d->c_in_ld & 3) || (d->k_pad % BK) || d->k_pad < d->ksize * d->ksize * d->c_in_ld)
         return BTS_ERR_INVALID;
     if (d->k_pad >= 65536) return BTS_ERR_UNSUPPORTED;
-    if ((d->x_pix_stride & 3) || d->x_pix_stride < d->c_in_ld) return BTS_ERR_INVALID;
+    if ((d->x_pix_stride & 3) || d->x_pix_stride < d->c_in_ld - (d->n_tail > 0 ? 4 : 0)) return BTS_ERR_INVALID;
     if ((d->c_out_pad & 31) || d->c_out_pad < d->c_out) return BTS_ERR_INVALID;
     if (((uintptr_t)d->x & 15) || ((uintptr_t)d->w & 15)) return BTS_ERR_INVALID;
     if ((d->pre_scale && (((uintptr_t)d->pre_scale & 15) || !d->pre_shift || ((uintptr_t)d->pre_shift & 15))))
@@ -732,6 +734,16 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     a.n_ntiles = 0; a.tiles_per_class = 0;
     a.n_classes = a.subpix ? 4 : 1; a.bundled = 0;
     a.res = d->res; a.res_pix_stride = d->res_pix_stride;
+    a.n_tail = d->n_tail;
+    for (int j = 0; j < 4; ++j) a.tail[j] = d->n_tail > 0 ? d->tail_planes[j < d->n_tail ? j : 0] : nullptr;
+    if (d->n_tail < 0 || d->n_tail > 4) return BTS_ERR_INVALID;
+    if (d->n_tail > 0) {
+        // the planes supply channels [c_in_ld-4, c_in_ld-4+n_tail) of the packed K axis; only the halo-tile kernel reads them
+        if (d->ksize != 3 || d->pad != 1 || d->stride != 1 || d->dil != 1 || d->up != 1 || d->subpixel || d->n_bundles > 1)
+            return BTS_ERR_UNSUPPORTED;
+        if (d->c_in_ld < 8 || d->x_pix_stride < d->c_in_ld - 4) return BTS_ERR_INVALID;
+        for (int j = 0; j < d->n_tail; ++j) if (!d->tail_planes[j] || ((uintptr_t)d->tail_planes[j] & 3)) return BTS_ERR_INVALID;
+    }
     if (d->res && (d->y_nchw || d->res_pix_stride < d->c_out)) return BTS_ERR_INVALID;
     if (d->n_bundles > 1) {
         if (d->subpixel || d->y_nchw || d->up != 1) return BTS_ERR_INVALID;
@@ -756,6 +768,11 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     const int prec_env = knobs().precision;
     const int prec = prec_env >= 0 ? prec_env : d->precision;
     if (prec != 0 && prec != 1) return BTS_ERR_INVALID;
+    if (a.n_tail > 0) {   // planar tail operand: always the halo-tile kernel (fp32-input MFMA whatever `precision` says)
+        if (bn == 128) return launch_halo<128, 4, 2, 32, 3, true>(a, nchw, s);
+        if (bn == 32) return launch_halo<32, 4, 1, 32, 3, true>(a, nchw, s);
+        return launch_halo<64, 4, 2, 32, 3, true>(a, nchw, s);
+    }
     if (prec == 1) {
         if (bn == 48) bn = 64;                       // the 16x16x4 48-wide tile has no bf16x3 twin: pad to 64
         // LDS buffering: the planes take 6 B per element, and with ONE buffer per workgroup (two barriers per K-step,

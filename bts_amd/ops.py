@@ -373,8 +373,12 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
                  y2d: Optional[torch.Tensor] = None, y_nchw: Optional[torch.Tensor] = None,
                  tag: str = "conv", c_in_real: Optional[int] = None, stride: int = 1, pad: Optional[int] = None,
                  y2_2d: Optional[torch.Tensor] = None, subpixel: bool = False,
-                 splitk_ws: Optional[torch.Tensor] = None, res2d: Optional[torch.Tensor] = None, n_bundles: int = 1):
+                 splitk_ws: Optional[torch.Tensor] = None, res2d: Optional[torch.Tensor] = None, n_bundles: int = 1,
+                 tail_planes: Optional[Sequence[torch.Tensor]] = None):
     """One fused convolution (see bts_conv_desc in include/bts_hip.h).
+    ``tail_planes``: 1..4 contiguous one-channel maps ([B,1,h_in,w_in] or [B,h_in,w_in]) that supply the LAST input
+    channels of the reference's concatenated input (bts.py:260, 274, 287) without ever being copied into the NHWC
+    buffer: x2d then holds c_in_ld - 4 channels and w_packed is packed with c_in_ld = (buffer channels) + 4.
     ``subpixel``: w_packed comes from pack_upconv_subpixel; computes nearest-2x + conv3x3 (pass ksize=3, up=2).
 
     x2d: [B*h_in*w_in, C>=c_in_ld] NHWC view.  Exactly one of y2d ([B*H*W, c_out] NHWC view) /
@@ -384,8 +388,9 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     c_out are PER BUNDLE, x2d / y2d hold all n_bundles*c_in_ld / n_bundles*c_out channels)."""
     xs, xc = _rows2d(x2d, "conv_forward")
     _need(w_packed, "conv_forward")
+    n_tail = len(tail_planes) if tail_planes else 0
     if c_in_ld is None:
-        c_in_ld = xc
+        c_in_ld = xc + (4 if n_tail else 0)
     flops_taps = ksize * ksize
     if subpixel:
         if ksize != 3 or up != 2 or dil != 1 or stride != 1 or w_packed.dim() != 3 or w_packed.shape[0] != 4:
@@ -403,8 +408,15 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     if k_pad != round_up(taps * c_in_ld, 32) or not w_packed.is_contiguous():
         raise BtsHipError("conv_forward: packed weight [%d,%d] does not match ksize %d / c_in_ld %d"
                           % (c_out_pad, k_pad, ksize, c_in_ld))
-    if c_in_ld % 4 or c_in_ld * n_bundles > xc or x2d.shape[0] != B * h_in * w_in:
+    if c_in_ld % 4 or (c_in_ld - (4 if n_tail else 0)) * n_bundles > xc or x2d.shape[0] != B * h_in * w_in:
         raise BtsHipError("conv_forward: bad input view (c_in_ld %d, view %s)" % (c_in_ld, tuple(x2d.shape)))
+    if n_tail:
+        if n_tail > 4 or ksize != 3 or stride != 1 or dil != 1 or up != 1 or subpixel or n_bundles > 1:
+            raise BtsHipError("conv_forward: tail_planes need a plain 3x3 / stride 1 / dilation 1 convolution and at most 4 planes")
+        for t in tail_planes:
+            _need(t, "conv_forward")
+            if t.numel() != B * h_in * w_in or not t.is_contiguous():
+                raise BtsHipError("conv_forward: every tail plane must be a contiguous [B,1,h_in,w_in] map")
     if pad is None:
         pad = dil * (ksize // 2)
     H = (h_in * up + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
@@ -418,6 +430,9 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     keep = []
     d.n_bundles = n_bundles if n_bundles > 1 else 0
     d.precision = _conv_precision
+    d.n_tail = n_tail
+    for j in range(n_tail):
+        d.tail_planes[j] = tail_planes[j].data_ptr()
     for name, pair, n in (("pre", pre, c_in_ld * n_bundles), ("e1", e1, c_out_pad * n_bundles), ("e2", e2, c_out_pad * n_bundles)):
         if pair is not None:
             s, b = pair

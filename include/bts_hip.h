@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 5
+#define BTS_HIP_ABI_VERSION 6
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -158,6 +158,14 @@ typedef struct bts_conv_desc {
                                 pieces on the way to LDS, six bf16 MFMAs per product block, fp32 accumulation; the
                                 result differs from mode 0 only by fp32 rounding (measured 1.2e-6 vs 1.1e-6 of
                                 max|result| against fp64), at up to 2.6x the MFMA rate.  Same inputs, outputs, tiles. */
+    const float* tail_planes[4];  /* planar tail operand: n_tail (1..4) extra input channels that live in dense one-channel
+                                planes [B,h_in,w_in] instead of the NHWC buffer -- the LPG depth maps / reduc1x1 that the
+                                reference concatenates behind the features (pytorch/bts.py:260, 274, 287: cat[upconv3, skip,
+                                depth_8x8_scaled_ds] ...).  They are channels [c_in_ld-4, c_in_ld-4+n_tail) of the packed K
+                                axis (c_in_ld = buffer channels + 4; weights of the unused tail slots are zero), x then
+                                only needs c_in_ld-4 channels.  3x3, pad 1, stride 1, dil 1, up 1 only (the decoder's
+                                conv3 / conv2 / conv1); computed on the fp32-input MFMA whatever `precision` says.         */
+    int   n_tail;              /* 0 = no tail                                                                              */
 } bts_conv_desc;
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);

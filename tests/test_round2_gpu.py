@@ -359,3 +359,48 @@ def test_config5_densenet161_train_step_b4_352x704_vs_cpu():
              errs32[int(0.9 * (len(errs32) - 1))]))
     assert len(per) > 500
     assert_grads_close(per, l2, "densenet161 B=4 352x704 / fp64", fp32_floor=(per32, l2_32))
+
+
+# ------------------------------------------------------------------------------------- planar tail operand (conv3/2/1)
+@pytest.mark.parametrize("c_main,n_tail,cout,shape,nchw", [(224, 1, 128, (2, 22, 76), False), (160, 1, 64, (1, 44, 152), False),
+                                                          (32, 4, 32, (2, 40, 72), True), (32, 4, 32, (1, 8, 8), True),
+                                                          (64, 2, 64, (3, 5, 37), False), (8, 3, 128, (1, 12, 33), False)])
+def test_conv_planar_tail_vs_torch(c_main, n_tail, cout, shape, nchw):
+    """bts_conv_desc.tail_planes: the last n_tail input channels of a 3x3 convolution come from dense one-channel planes
+    (bts.py:260, 274, 287 concatenate depth maps behind the features).  Must equal the convolution of the concatenated
+    tensor -- at tile-unfriendly sizes, with NCHW output, and with unused tail slots never touching the result."""
+    from bts_amd import ops
+    B, h, w = shape
+    g = torch.Generator().manual_seed(c_main + n_tail)
+    feat = torch.randn((B, c_main, h, w), generator=g)
+    planes = [torch.randn((B, 1, h, w), generator=g) * 3 for _ in range(n_tail)]
+    wt = torch.randn((cout, c_main + n_tail, 3, 3), generator=g) * 0.05
+    ref = torch.nn.functional.elu(torch.nn.functional.conv2d(torch.cat([feat] + planes, 1).double(), wt.double(), padding=1))
+    x2d = feat.permute(0, 2, 3, 1).reshape(B * h * w, c_main).contiguous().cuda()
+    wp, cop, cld = ops.pack_conv_weight(wt.cuda(), c_in_ld=c_main + 4)
+    assert cld == c_main + 4
+    tails = [p.cuda() for p in planes]
+    if nchw:
+        y = torch.empty((B, cout, h, w), device="cuda")
+        ops.conv_forward(x2d, B, h, w, wp, cout, 3, act=ops.ACT_ELU, y_nchw=y, tail_planes=tails)
+        got = y.cpu().double()
+    else:
+        y = torch.empty((B * h * w, cout), device="cuda")
+        ops.conv_forward(x2d, B, h, w, wp, cout, 3, act=ops.ACT_ELU, y2d=y, tail_planes=tails)
+        got = y.cpu().double().reshape(B, h, w, cout).permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-6, err
+    # +-inf in a REAL plane propagates exactly as in the reference formulation (the LPG maps hold +-inf where a
+    # denominator is exactly 0, bts.py:168-173): same non-finite mask, same finite values elsewhere
+    planes[0][0, 0, h // 2, w // 2] = float("inf")
+    ref2 = torch.nn.functional.conv2d(torch.cat([feat] + planes, 1), wt, padding=1)
+    tails = [p.cuda() for p in planes]
+    y2 = torch.empty((B * h * w, cout), device="cuda")
+    ops.conv_forward(x2d, B, h, w, wp, cout, 3, y2d=y2, tail_planes=tails)
+    got2 = y2.cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2)
+    assert torch.equal(torch.isfinite(got2), torch.isfinite(ref2))
+    fin = torch.isfinite(ref2)
+    assert (got2[fin] - ref2[fin]).abs().max().item() <= 1e-4 * ref2[fin].abs().max().item()
+    from bts_amd._lib import BtsHipError
+    with pytest.raises(BtsHipError):
+        ops.conv_forward(x2d, B, h, w, wp, cout, 3, dil=2, y2d=y2, tail_planes=tails)
