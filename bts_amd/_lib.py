@@ -17,9 +17,10 @@ SYMBOLS = (
     "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32", "bts_maxpool3x3s2_nhwc_f32", "bts_bn_relu_avgpool2_nhwc_f32",
     "bts_conv_wgrad_f32", "bts_bn_train_ws_floats", "bts_bn_train_stats_f32", "bts_bn_apply_nhwc_f32", "bts_bn_train_bwd_f32",
     "bts_pack_weights_blocks", "bts_pack_weights_f32", "bts_eval_ws_doubles", "bts_eval_depth_metrics_f32",
+    "bts_reduc_lpg_fwd_f32",
 )
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ConvDesc(C.Structure):
@@ -100,6 +101,8 @@ def load():
     lib.bts_lpg_fused_fwd_f32.argtypes = [vp, i, i, i, i, i, f, vp, vp, i, l, vp, vp]
     lib.bts_reduc_fwd_f32.restype = i
     lib.bts_reduc_fwd_f32.argtypes = [vp, l, l, i, i, vp, l, f, i, i, vp, vp]
+    lib.bts_reduc_lpg_fwd_f32.restype = i
+    lib.bts_reduc_lpg_fwd_f32.argtypes = [vp, l, i, i, i, i, i, vp, l, f, i, vp, vp, vp, vp, vp]
     lib.bts_conv_fwd_f32.restype = i
     lib.bts_conv_fwd_f32.argtypes = [C.POINTER(ConvDesc), vp]
     lib.bts_conv_wgrad_f32.restype = i

@@ -211,6 +211,11 @@ class reduction_1x1(nn.Sequential):
         ops.reduc_forward_nhwc(x2d, self.c_in, self.c_first_out, self.packed(), self.max_depth, self.is_final,
                                normalize, out)
 
+    def run_lpg_nhwc(self, x2d, B, h, w, upratio, depth_scaled, ds_out, abs_min):
+        """This reduction + normalize + LPG + /max_depth (+ downsampled plane) as ONE launch (bts.py:249-256)."""
+        ops.reduc_lpg_forward(x2d, B, h, w, self.c_in, self.c_first_out, self.packed(), self.max_depth, upratio,
+                              depth_scaled, ds_out=ds_out, abs_min=abs_min)
+
     def forward(self, net):
         if self.training:
             return train.reduction_forward(self, net)
@@ -340,15 +345,12 @@ class bts(nn.Module):
             x8=z(n8, nf // 2 + f[2] + 5 * (nf // 4) + nf // 2),  # [upconv4 | skip2 | d3 d6 d12 d18 d24 | iconv4]
             mid=z(n8, nf // 2),
             daspp_feat=z(n8, nf // 4),
-            plane8=z(n8, 4),
             cat3=z(n4, nf // 4 + f[1]),                          # [upconv3 | skip1]; depth_8x8_scaled_ds is the plane ds8
             ds8=torch.zeros(n4, dtype=torch.float32, device=device),
             iconv3=z(n4, nf // 4),
-            plane4=z(n4, 4),
             cat2=z(n2, nf // 8 + f[0]),                          # [upconv2 | skip0]; depth_4x4_scaled_ds is the plane ds4
             ds4=torch.zeros(n2, dtype=torch.float32, device=device),
             iconv2=z(n2, nf // 8),
-            plane2=z(n2, 4),
             cat1=z(n1, nf // 16),                                # upconv1; reduc1x1 / d2 / d4 / d8 are read as planes
             # scratch for split-K of under-filled launches (bts_conv_desc.splitk_ws): 8 splits x [n16, nf]
             splitk=torch.empty(8 * n16 * nf, dtype=torch.float32, device=device),
@@ -443,32 +445,27 @@ class bts(nn.Module):
             return torch.empty((B, c, H, W), dtype=torch.float32, device=dev)
 
         # 8x8 scale (bts.py:249-256)
-        self.reduc8x8.run_nhwc(ws["daspp_feat"], ws["plane8"], True)
         depth_8x8_scaled = out_tensor(0, 1)
         a8 = am()
         c3 = ws["cat3"]
-        ops.lpg_fused_forward(ws["plane8"], B, h8, w8, 8, md, False, depth_8x8_scaled,
-                              ds_out=ws["ds8"], ds_factor=4, ds_pix_stride=1, abs_min=a8)        # dense plane
+        self.reduc8x8.run_lpg_nhwc(ws["daspp_feat"], B, h8, w8, 8, depth_8x8_scaled, ws["ds8"], a8)   # ONE launch
         self.lpg8x8.abs_min = a8
 
         # H/4 (bts.py:258-270)
         conv(self.upconv3.packed(), ws["daspp_feat"], h8, w8, q, y2d=c3[:, :q], up=2, e2=P["bn3"])
         conv("conv3", c3, h4, w4, q, y2d=ws["iconv3"], c_in_real=q + f[1] + 1, tail=[ws["ds8"]])
-        self.reduc4x4.run_nhwc(ws["iconv3"], ws["plane4"], True)
         depth_4x4_scaled = out_tensor(1, 1)
         a4 = am()
         c2 = ws["cat2"]
-        ops.lpg_fused_forward(ws["plane4"], B, h4, w4, 4, md, False, depth_4x4_scaled,
-                              ds_out=ws["ds4"], ds_factor=2, ds_pix_stride=1, abs_min=a4)
+        self.reduc4x4.run_lpg_nhwc(ws["iconv3"], B, h4, w4, 4, depth_4x4_scaled, ws["ds4"], a4)
         self.lpg4x4.abs_min = a4
 
         # H/2 (bts.py:272-283)
         conv(self.upconv2.packed(), ws["iconv3"], h4, w4, nf // 8, y2d=c2[:, :nf // 8], up=2, e2=P["bn2"])
         conv("conv2", c2, h2, w2, nf // 8, y2d=ws["iconv2"], c_in_real=nf // 8 + f[0] + 1, tail=[ws["ds4"]])
-        self.reduc2x2.run_nhwc(ws["iconv2"], ws["plane2"], True)
         depth_2x2_scaled = out_tensor(2, 1)
         a2 = am()
-        ops.lpg_fused_forward(ws["plane2"], B, h2, w2, 2, md, False, depth_2x2_scaled, abs_min=a2)
+        self.reduc2x2.run_lpg_nhwc(ws["iconv2"], B, h2, w2, 2, depth_2x2_scaled, None, a2)
         self.lpg2x2.abs_min = a2
 
         # full resolution (bts.py:285-291)

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "common.h"
+#include "lpg_math.h"
 
 // hipcc defaults to -ffp-contract=fast, which would fuse n1*u + ... into FMAs and break bit-parity
 // with the reference's separately rounded mul/add kernels.  (HIP's __fmul_rn/__fadd_rn do NOT help:
@@ -26,13 +27,6 @@ __device__ __forceinline__ float lpg_den(float n1, float n2, float n3, float u, 
     return (n1 * u + n2 * v) + n3;   // contraction is off for this file
 }
 
-__device__ __forceinline__ float lpg_clamp(float d) {
-    const float eps = 1e-3f;
-    if (d > 0.f && d < eps) d = eps;          // bts.py:170
-    if (d < 0.f && d > -eps) d = -eps;        // bts.py:171
-    return d;
-}
-
 // block-min of |den| then ONE atomic per block: same-address atomics serialise in L2 (~12 ns each on
 // MI355X), so blocks are fat (16 waves) and the grid is capped at 512.
 // NaN: the reference's `torch.abs(divided).min()` (bts.py:167) returns NaN as soon as one denominator is NaN, and
@@ -41,10 +35,9 @@ __device__ __forceinline__ float lpg_clamp(float d) {
 // order, and "saw a NaN" is the negative key 0xffc00000 (a quiet NaN with the sign bit set), which is below every
 // real key and still reads back as NaN from the caller's float scalar.
 constexpr int LPG_ROWS = 16;                       // block = 64 x 16 threads
-constexpr int LPG_NAN_KEY = (int)0xffc00000u;
 __device__ __forceinline__ void publish_abs_min(float m, bool saw_nan, int* abs_min_key) {
     __shared__ int wave_min[LPG_ROWS];
-    int k = saw_nan ? LPG_NAN_KEY : __float_as_int(m);
+    int k = lpg_min_key(m, saw_nan);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) k = min(k, __shfl_xor(k, off, 64));
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
@@ -144,14 +137,12 @@ __global__ __launch_bounds__(64 * LPG_ROWS) void lpg_fused_lean_kernel(const flo
                                                                        int ds_factor, int ds_pix_stride,
                                                                        int* __restrict__ abs_min_bits) {
     const int W = w * K, W4 = W >> 2;
-    constexpr float invK = 1.0f / (float)K;
     constexpr int CELLS = K >= 4 ? 1 : 2;
     float amin = __uint_as_float(0x7f800000u);
     bool saw_nan = false;
     for (int row = blockIdx.x * LPG_ROWS + threadIdx.y; row < nrows; row += gridDim.x * LPG_ROWS) {
         const int b = row / H, r = row - b * H;
         const int cr = r / K;
-        const float v = ((float)(r - cr * K) - (float)(K - 1) * 0.5f) * invK;
         const float4* prow = plane4 + (size_t)(b * h + cr) * w;
         float* orow = out + (size_t)row * W;
         const bool ds_row = ds_out != nullptr && (r % ds_factor) == 0;
@@ -163,16 +154,10 @@ __global__ __launch_bounds__(64 * LPG_ROWS) void lpg_fused_lean_kernel(const flo
             for (int ci = 0; ci < CELLS; ++ci) {
                 const int cb = c0 + ci * (4 / CELLS);
                 const float4 q = prow[cb / K];
-                const float base = fmaf(q.y, v, q.z);                       // n2*v + n3
-                const float u0 = ((float)(cb % K) - (float)(K - 1) * 0.5f) * invK;
+                float part[4 / CELLS];
+                lpg_cell_outputs<K, 4 / CELLS>(q.x, q.y, q.z, q.w, r - cr * K, cb % K, max_depth, part, amin, saw_nan);
 #pragma unroll
-                for (int i = 0; i < 4 / CELLS; ++i) {
-                    float d = fmaf(q.x, u0 + (float)i * invK, base);        // n1*u + n2*v + n3   (bts.py:166)
-                    amin = fminf(amin, fabsf(d));                           // bts.py:167
-                    saw_nan |= d != d;
-                    d = lpg_clamp(d);                                       // bts.py:168-171
-                    res[ci * (4 / CELLS) + i] = q.w * __builtin_amdgcn_rcpf(d * max_depth);   // bts.py:173,255
-                }
+                for (int i = 0; i < 4 / CELLS; ++i) res[ci * (4 / CELLS) + i] = part[i];
             }
             *reinterpret_cast<float4*>(orow + c0) = make_float4(res[0], res[1], res[2], res[3]);
             if (ds_row) {                                                   // nearest [::f, ::f]   (bts.py:256,270)

@@ -230,6 +230,40 @@ def reduc_forward_nhwc(x2d: torch.Tensor, c_in: int, c_first_out: int, w_frag: t
     return out
 
 
+def reduc_lpg_forward(x2d: torch.Tensor, B: int, h: int, w: int, c_in: int, c_first_out: int, w_frag: torch.Tensor,
+                      max_depth: float, upratio: int, depth_scaled: torch.Tensor, ds_out: Optional[torch.Tensor] = None,
+                      abs_min: Optional[torch.Tensor] = None, plane4: Optional[torch.Tensor] = None):
+    """One scale of the decoder's LPG stage in ONE launch (bts_reduc_lpg_fwd_f32): reduction_1x1 chain -> normalize ->
+    LPG -> /max_depth (+ the nearest-downsampled plane, + abs_min).  x2d: [B*h*w, >=c_in] NHWC view; depth_scaled:
+    contiguous [B,1,h*k,w*k]; ds_out: contiguous [B*2h*2w] plane (k = 8, 4) or None."""
+    stride, cview = _rows2d(x2d, "reduc_lpg_forward")
+    _need(depth_scaled, "reduc_lpg_forward")
+    _need(w_frag, "reduc_lpg_forward")
+    k = int(upratio)
+    npix = B * h * w
+    if cview < c_in or x2d.shape[0] != npix:
+        raise BtsHipError("reduc_lpg_forward: bad input view %s for B=%d %dx%d, %d channels" % (tuple(x2d.shape), B, h, w, c_in))
+    if depth_scaled.numel() != npix * k * k or not depth_scaled.is_contiguous():
+        raise BtsHipError("reduc_lpg_forward: depth_scaled must be contiguous [B,1,h*k,w*k]")
+    if ds_out is not None:
+        _need(ds_out, "reduc_lpg_forward")
+        if k == 2 or ds_out.numel() != npix * 4 or not ds_out.is_contiguous():
+            raise BtsHipError("reduc_lpg_forward: ds_out must be a contiguous [B,2h,2w] plane (k = 8 or 4 only)")
+    if plane4 is not None and (plane4.numel() != npix * 4 or not plane4.is_contiguous()):
+        raise BtsHipError("reduc_lpg_forward: plane4 must be contiguous [B*h*w,4]")
+    chain = reduc_chain(c_in, c_first_out)
+    macs = sum(ci * (co if co > 0 else 3) for ci, co in chain)
+    nbytes = 4.0 * (npix * c_in + macs + npix * k * k + (npix * 4 if ds_out is not None else 0))
+    with torch.cuda.device(x2d.device):
+        rc = _launch("reduc_lpg_kernel<%d,%d,k%d>" % (c_in, c_first_out, k), "reduc_lpg", 2.0 * npix * macs + 8.0 * npix * k * k, nbytes,
+                     lambda: _lib.load().bts_reduc_lpg_fwd_f32(_ptr(x2d), stride, B, h, w, int(c_in), int(c_first_out),
+                                                               _ptr(w_frag), w_frag.numel(), float(max_depth), k,
+                                                               _ptr(plane4), _ptr(depth_scaled), _ptr(ds_out),
+                                                               _ptr(abs_min), _stream(x2d)))
+    _lib.check(rc, "bts_reduc_lpg_fwd_f32")
+    return depth_scaled
+
+
 # ---------------------------------------------------------------------------- layout
 def nchw_to_nhwc(src: torch.Tensor, dst2d: torch.Tensor, relu: bool = False):
     """src [B,C,H,W] contiguous -> dst2d [B*H*W, C] view (channel slice of an NHWC buffer)."""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 6
+#define BTS_HIP_ABI_VERSION 7
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -91,6 +91,21 @@ int bts_lpg_fused_fwd_f32(const float* plane4, int B, int h, int w, int upratio,
 int bts_reduc_fwd_f32(const float* x, long x_pix_stride, long npix, int c_in, int c_first_out,
                       const float* w_frag, long w_frag_floats, float max_depth, int is_final,
                       int normalize, float* out, bts_stream_t stream);
+
+/* reduction_1x1 (non-final) -> F.normalize -> local_planar_guidance -> /max_depth -> nearest downsample in ONE launch:
+ * one scale of pytorch/bts.py:249-256 (8x8), 263-270 (4x4), 277-283 (2x2).  The plane equations go from the chain's
+ * registers straight into the k x k depth block of their cell; they reach HBM only if `plane4` is given.
+ *   x            : NHWC activations [B*h*w, >= c_in] (pixel stride x_pix_stride)
+ *   (c_in, c_first_out, upratio) : (128,128,8), (128,64,4) or (64,32,2) -- the three scales of bts_size 512
+ *   plane4       : optional [B*h*w,4] (n1,n2,n3 normalised, n4) for callers that want the plane equation; NULL to skip
+ *   depth_scaled : [B,1,h*k,w*k] = lpg(plane)/max_depth                                  (bts.py:255, 269, 283)
+ *   ds_out       : optional dense plane [B,2h,2w] = depth_scaled[..., ::k/2, ::k/2]        (bts.py:256, 270: scale_factor
+ *                  0.25 at k=8, 0.5 at k=4); must be NULL for k=2
+ *   abs_min      : optional 1-float device scalar <- min |den| over the batch, NaN if any denominator is NaN (bts.py:167)
+ */
+int bts_reduc_lpg_fwd_f32(const float* x, long x_pix_stride, int B, int h, int w, int c_in, int c_first_out,
+                          const float* w_frag, long w_frag_floats, float max_depth, int upratio,
+                          float* plane4, float* depth_scaled, float* ds_out, float* abs_min, bts_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * NHWC implicit-GEMM convolution on fp32-input MFMA (v_mfma_f32_32x32x2_f32), with fused
