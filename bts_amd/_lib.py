@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbts_hip.so")
@@ -17,10 +18,10 @@ SYMBOLS = (
     "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32", "bts_maxpool3x3s2_nhwc_f32", "bts_bn_relu_avgpool2_nhwc_f32",
     "bts_conv_wgrad_f32", "bts_bn_train_ws_floats", "bts_bn_train_stats_f32", "bts_bn_apply_nhwc_f32", "bts_bn_train_bwd_f32",
     "bts_pack_weights_blocks", "bts_pack_weights_f32", "bts_eval_ws_doubles", "bts_eval_depth_metrics_f32",
-    "bts_reduc_lpg_fwd_f32",
+    "bts_reduc_lpg_fwd_f32", "bts_plan_run",
 )
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ConvDesc(C.Structure):
@@ -73,9 +74,37 @@ def source_hash() -> str:
 
 
 _lib = None
+_tls = threading.local()
+
+
+class recording:
+    """While active (this thread only), load() hands out `proxy` instead of the library: bts_amd/plan.py records the
+    calls a forward makes through it."""
+
+    def __init__(self, proxy):
+        self.proxy = proxy
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "proxy", None)
+        _tls.proxy = self.proxy
+        return self.proxy
+
+    def __exit__(self, *exc):
+        _tls.proxy = self.prev
+        return False
+
+
+def is_recording() -> bool:
+    return getattr(_tls, "proxy", None) is not None
 
 
 def load():
+    """The loaded library (or the recording proxy standing in for it, see `recording`)."""
+    proxy = getattr(_tls, "proxy", None)
+    return proxy if proxy is not None else load_real()
+
+
+def load_real():
     """Load the library once; raise loudly if it is not built."""
     global _lib
     if _lib is not None:

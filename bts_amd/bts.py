@@ -30,6 +30,8 @@ from ._lib import BtsHipError
 from . import encoders
 from .encoders import build_base_model
 from .workspace import PackCache, WorkspaceCache, tensor_fingerprint
+from .plan import PlanCache
+from . import _lib as _lib_mod
 
 
 # ----------------------------------------------------------------- helpers kept from the reference API
@@ -534,6 +536,10 @@ class BtsModel(nn.Module):
         self.native_encoder = True          # set False to force the torch encoder (A/B, debugging)
         self.sub_batches = 4                # concurrent sub-batches (own HIP stream + workspace each); 1 = off
                                             # (MI355X, B=16: 1 -> 54.7, 2 -> 48.4, 4 -> 47.6, 8 -> 51.5 ms/step)
+        self.use_plans = False              # True: record each (shape, slot) forward once, replay it with ONE library
+                                            # call per forward afterwards (bts_amd/plan.py, bts_plan_run): the eager
+                                            # B=1 loop of bts_test.py:127-147 without ~120 ctypes crossings per frame
+        self._plans = PlanCache()
         self._origin = [self]               # reaches DataParallel replicas through replicate()'s shallow __dict__ copy
         self._enc_plans = {}                # device -> DenseNetHip / ResNetHip (packs + workspaces), shared with replicas
 
@@ -542,6 +548,11 @@ class BtsModel(nn.Module):
                 and isinstance(self.encoder.base_model, (nn.Sequential, encoders.ResNet)))
 
     def _forward_native(self, x, focal, slot, outs=None):
+        if self.use_plans and ops._trace is None and not _lib_mod.is_recording():
+            return self._plans.forward(self, x, focal, slot, outs)
+        return self._forward_native_eager(x, focal, slot, outs)
+
+    def _forward_native_eager(self, x, focal, slot, outs=None):
         from .encoder_hip import DenseNetHip, ResNetHip
         base = self.encoder.base_model
         src_base = self._origin[0].encoder.base_model      # a replica's packs are fingerprinted on the source model

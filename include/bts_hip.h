@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 7
+#define BTS_HIP_ABI_VERSION 8
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -324,6 +324,51 @@ int bts_eval_depth_metrics_f32(const float* pred, int B, int Hp, int Wp, const f
                                int top, int left, float min_depth_eval, float max_depth_eval,
                                int y0, int y1, int x0, int x1, double* ws, long ws_doubles,
                                double* per_frame, double* accum, bts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One-call execution of a recorded forward ("plan").  A BtsModel forward is a fixed sequence of ~120 (B=1) to ~460
+ * (B=16, four sub-batches) launches of the entry points above with arguments that depend only on the input shape:
+ * workspaces, packed weights and dims are fixed per shape, only the caller's input / output tensors move.  The host
+ * records that sequence once per shape as an array of `bts_op` records -- bts_amd/plan.py -- and replays it with ONE call per stream:
+ * the reference's inference loop is batch 1, eager (pytorch/bts_test.py:127-147), where the per-launch host path is
+ * what bounds the frame rate.
+ *
+ *   ops      : the recorded calls, in order; each holds the argument list of its entry point (stream excluded)
+ *   patches  : pointer fields that refer to per-call tensors: field := slots[slot] + delta (bytes), applied IN PLACE
+ *              to `ops` before the launches (idempotent; a plan must not be replayed by two threads at once)
+ *   slots    : base device pointers of this call's tensors (image, focal, the six outputs, abs_min scalars ...)
+ * Returns the first non-zero code of an entry point (the remaining ops are not enqueued), 0 otherwise.
+ */
+enum { BTS_OP_CONV = 1, BTS_OP_REDUC = 2, BTS_OP_REDUC_LPG = 3, BTS_OP_LPG_FUSED = 4, BTS_OP_NCHW_TO_NHWC = 5,
+       BTS_OP_NHWC_TO_NCHW = 6, BTS_OP_MAXPOOL = 7, BTS_OP_BN_RELU_AVGPOOL = 8, BTS_OP_GET_DEPTH = 9, BTS_OP_LPG = 10 };
+
+typedef struct bts_op {
+    int kind;          /* BTS_OP_*                                                              */
+    int failed_code;   /* out: the entry point's return code when it was the one that failed   */
+    union {
+        bts_conv_desc conv;
+        struct { const float* x; long x_pix_stride; long npix; int c_in, c_first_out; const float* w_frag; long w_frag_floats;
+                 float max_depth; int is_final, normalize; float* out; } reduc;
+        struct { const float* x; long x_pix_stride; int B, h, w, c_in, c_first_out; const float* w_frag; long w_frag_floats;
+                 float max_depth; int upratio; float* plane4; float* depth_scaled; float* ds_out; float* abs_min; } reduc_lpg;
+        struct { const float* plane4; int B, h, w, upratio, normalize; float max_depth; float* depth_scaled; float* ds_out;
+                 int ds_factor; long ds_pix_stride; float* abs_min; } lpg_fused;
+        struct { const float* plane_eq; int B, h, w, upratio; float* depth; float* abs_min; } lpg;
+        struct { const float* src; int B, C; long HW; float* dst; long dst_pix_stride; int relu; } nchw_to_nhwc;
+        struct { const float* src; long src_pix_stride; int B, C; long HW; float* dst; } nhwc_to_nchw;
+        struct { const float* src; long src_pix_stride; int B, h, w, C; float* dst; long dst_pix_stride; float* dst2;
+                 long dst2_pix_stride; } maxpool;
+        struct { const float* src; long src_pix_stride; int B, h, w, C; const float* scale; const float* shift; float* dst;
+                 long dst_pix_stride; } avgpool;
+        struct { const float* iconv1; const float* w; int B, C, H, W; float max_depth; const float* focal;
+                 float* final_depth; } get_depth;
+    } u;
+} bts_op;
+
+typedef struct bts_plan_patch { int op; int field_offset; int slot; int reserved; long delta; } bts_plan_patch;
+
+int bts_plan_run(bts_op* ops, int n_ops, const bts_plan_patch* patches, int n_patches, void* const* slots, int n_slots,
+                 bts_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -187,3 +187,22 @@ def test_caches_survive_deepcopy_pickle_and_replication():
     assert "a" not in wc and len(wc) == 4                        # unpinned and least recently used: a goes, e and f stay
     wc.get("g", dict)
     assert all(k in wc for k in "bcfg") and len(wc) == 4
+
+
+def test_plan_op_layout_matches_header(tmp_path):
+    """bts_amd/plan.py mirrors `bts_op` / `bts_plan_patch` (include/bts_hip.h) with ctypes structures derived from the
+    declared argtypes: sizes and the union offset must equal what a C compiler makes of the header."""
+    import subprocess
+    from bts_amd import plan
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bts_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", '
+                   'sizeof(bts_op), offsetof(bts_op, u), sizeof(bts_plan_patch), sizeof(bts_conv_desc), '
+                   'offsetof(bts_op, u.reduc_lpg.abs_min));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    c_sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    plan._build_types()
+    rl = plan._structs["bts_reduc_lpg_fwd_f32"]
+    py_sizes = [ctypes.sizeof(plan._BtsOp), plan._BtsOp.u.offset, ctypes.sizeof(plan._BtsPatch),
+                ctypes.sizeof(plan._structs["bts_conv_fwd_f32"]), plan._BtsOp.u.offset + getattr(rl, "a14").offset]
+    assert c_sizes == py_sizes, (c_sizes, py_sizes)

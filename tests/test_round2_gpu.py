@@ -466,3 +466,51 @@ def test_reduc_lpg_one_launch_equals_two_launch_pipeline_and_oracle(c_in, c_firs
     from bts_amd._lib import BtsHipError
     with pytest.raises(BtsHipError):
         ops.reduc_lpg_forward(x2d, B, h, w, c_in, c_first, wf, md, 8 if k != 8 else 4, torch.empty((B, 1, h * 8, w * 8), device="cuda")[:, :, :h * (8 if k != 8 else 4), :w * (8 if k != 8 else 4)].contiguous())
+
+
+# --------------------------------------------------------------------------------------- one-call forward (plans)
+def test_planned_forward_equals_eager_and_follows_weight_changes():
+    """BtsModel.use_plans: the forward is recorded once per (shape, slot) and replayed with ONE bts_plan_run call.
+    Results must be bit-identical to the eager forward for new inputs, fresh output tensors every call (no static-output
+    contract), abs_min delivered, re-recorded after a weight change."""
+    m = _model("densenet121_bts").cuda()
+    with torch.no_grad():
+        for S, (B, H, W) in ((1, (1, 64, 96)), (2, (4, 64, 96)), (1, (2, 96, 64))):
+            m.sub_batches = S
+            m.use_plans = False
+            inputs = [(t(synth.image_batch(B, H, W, 60 + i)).cuda(), t(synth.focal_values(B, "kitti", 60 + i)).cuda()) for i in range(3)]
+            eager = []
+            for img, foc in inputs:
+                outs = m(img, foc)
+                eager.append(([o.clone() for o in outs], [m.decoder.lpg8x8.abs_min.item(), m.decoder.lpg4x4.abs_min.item(),
+                                                          m.decoder.lpg2x2.abs_min.item()]))
+            m.use_plans = True
+            rec0 = m._plans.recordings
+            got = [m(img, foc) for img, foc in inputs] + [m(*inputs[0])]
+            torch.cuda.synchronize()
+            assert m._plans.recordings == rec0 + S               # one plan per sub-batch slot, recorded on the first call only
+            for (ref, ref_am), outs in zip(eager + [eager[0]], got):
+                assert all(torch.equal(a, b) for a, b in zip(outs, ref))
+            assert got[0][4].data_ptr() != got[3][4].data_ptr()   # fresh outputs per call
+            am = [m.decoder.lpg8x8.abs_min.item(), m.decoder.lpg4x4.abs_min.item(), m.decoder.lpg2x2.abs_min.item()]
+            assert am == eager[0][1]
+        # weight change -> the plan (which points at the old packed weights) is re-recorded
+        img, foc = inputs[0]
+        before = [o.clone() for o in m(img, foc)]
+        for p in m.decoder.get_depth.parameters():
+            p.mul_(0.5)
+        rec1 = m._plans.recordings
+        after = m(img, foc)
+        m.use_plans = False
+        ref = m(img, foc)
+        assert m._plans.recordings == rec1 + 1
+        assert all(torch.equal(a, b) for a, b in zip(after, ref)) and not torch.equal(after[4], before[4])
+        # focal=None (non-KITTI heads never read it, bts.py:290-291) and the ResNeXt plan
+        n = _model("resnext50_bts", "nyu").cuda()
+        n.sub_batches = 1
+        x = t(synth.image_batch(1, 64, 64, 3)).cuda()
+        r0 = n(x, None)
+        n.use_plans = True
+        n(x, None)
+        r1 = n(x, None)
+        assert all(torch.equal(a, b) for a, b in zip(r0, r1))
