@@ -39,7 +39,7 @@ struct ConvKnobs {
     int no48, force_bm;                                    // BTS_CONV_NO48, BTS_CONV_BM
     int precision, emu_sb;                                 // BTS_CONV_PRECISION, BTS_CONV_EMU_SB (-1 = unset)
     int w8, w8s;                                           // BTS_CONV_W8, BTS_CONV_W8S
-    int halo;                                              // BTS_CONV_HALO: 0 off, 1 = halo-tile kernel where eligible unless split-K applies, 2 = also instead of split-K (default)
+    int halo;                                              // BTS_CONV_HALO: 0 off, 1 = halo-tile kernel where eligible unless split-K applies, 2 = also instead of split-K.  Default 1: on the deep 22x76 maps a frame has only 15 spatial tiles, so at batch 1 split-K fills the chip 7x better (53 vs 16 us per layer), and the choice may not depend on the batch (a frame's bits must not)
 };
 inline long env_long(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
 const ConvKnobs& knobs() {
@@ -48,7 +48,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_NO48", 0), (int)env_long("BTS_CONV_BM", 0),
                                 (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
                                 (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1),
-                                (int)env_long("BTS_CONV_HALO", 2)};
+                                (int)env_long("BTS_CONV_HALO", 1)};
     return k;
 }
 // floats per LDS row (32 + pad), chosen per MFMA shape so that the 16 rows a ds_read_b128 lane group touches

@@ -95,6 +95,7 @@ class _Proxy:
     """Stands in for the loaded library while a recording is active: forwards every call, keeps a copy of its arguments."""
 
     def __init__(self, lib, rec: _Recorder):
+        _build_types()
         self._lib, self._rec = lib, rec
 
     def __getattr__(self, name):
