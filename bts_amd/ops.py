@@ -274,7 +274,8 @@ def nchw_to_nhwc(src: torch.Tensor, dst2d: torch.Tensor, relu: bool = False):
     if cview != Cc or dst2d.shape[0] != B * H * W:
         raise BtsHipError("nchw_to_nhwc: destination view shape mismatch")
     with torch.cuda.device(src.device):
-        rc = _lib.load().bts_nchw_to_nhwc_f32(_ptr(src), B, Cc, H * W, _ptr(dst2d), stride, int(bool(relu)), _stream(src))
+        rc = _launch("nchw_to_nhwc_kernel", "layout", 0.0, 8.0 * src.numel(),
+                     lambda: _lib.load().bts_nchw_to_nhwc_f32(_ptr(src), B, Cc, H * W, _ptr(dst2d), stride, int(bool(relu)), _stream(src)))
     _lib.check(rc, "bts_nchw_to_nhwc_f32")
     return dst2d
 
@@ -667,8 +668,9 @@ def get_depth_forward(iconv1: torch.Tensor, weight: torch.Tensor, max_depth: flo
     elif tuple(out.shape) != (B, 1, H, W) or not out.is_contiguous():
         raise BtsHipError("get_depth_forward: out must be contiguous [B,1,H,W]")
     with torch.cuda.device(iconv1.device):
-        rc = _lib.load().bts_get_depth_f32(_ptr(iconv1), _ptr(weight), B, Cc, H, W, float(max_depth), _ptr(focal),
-                                           _ptr(out), _stream(iconv1))
+        rc = _launch("get_depth_kernel<%d>" % Cc, "get_depth", 2.0 * 9 * Cc * B * H * W, 4.0 * (Cc + 1) * B * H * W,
+                     lambda: _lib.load().bts_get_depth_f32(_ptr(iconv1), _ptr(weight), B, Cc, H, W, float(max_depth),
+                                                           _ptr(focal), _ptr(out), _stream(iconv1)))
     _lib.check(rc, "bts_get_depth_f32")
     return out
 
