@@ -69,9 +69,8 @@ def pmc_traffic(kernel):
     import glob
     import re
     from bts_amd import _lib
-    m = re.match(r"conv_fwd_kernel<(\d+),(\d+),(nhwc|nchw)>", kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not m or not files:
+    if not files:
         return None
     try:
         tab = json.load(open(files[-1]))
@@ -84,11 +83,27 @@ def pmc_traffic(kernel):
         src["hbm_bytes_per_launch"] = None
         src["stale"] = True
         return src
+    want = trace_to_rocprof_name(kernel)
     for k, v in tab.items():
-        mm = re.match(r"conv_fwd_kernel<(\d+),(\d+),\d+,\d+,\d+,(false|true)(?:,0)?>", k)   # trailing 0 = fp32-MFMA mode
-        if mm and mm.group(1) == m.group(1) and mm.group(2) == m.group(2) and (mm.group(3) == "true") == (m.group(3) == "nchw"):
+        if k != "_meta" and want is not None and re.fullmatch(want, k):
             src["hbm_bytes_per_launch"] = int(v["hbm_MB_per_launch"] * 1e6)
+            src["rocprof_kernel"] = k
             return src
+    return None
+
+
+def trace_to_rocprof_name(kernel):
+    """Regex for the rocprofv3 (demangled, spaces removed) name of a kernel label used by ops.KernelTrace:
+    conv_fwd_kernel<BM,BN,nhwc|nchw[,splitk]> -> conv_fwd_kernel<BM,BN,WM,WN,MF,false|true,0>;
+    conv_halo_kernel<BN,kK,nhwc|nchw[,tail]> -> conv_halo_kernel<BN,WM,WN,MF,K,false|true,false|true>."""
+    import re
+    m = re.match(r"conv_fwd_kernel<(\d+),(\d+),(nhwc|nchw)(,splitk)?>", kernel)
+    if m:
+        return r"conv_fwd_kernel<%s,%s,\d+,\d+,\d+,%s(,0)?>" % (m.group(1), m.group(2), "true" if m.group(3) == "nchw" else "false")
+    m = re.match(r"conv_halo_kernel<(\d+),k(\d),(nhwc|nchw)(,tail)?>", kernel)
+    if m:
+        return r"conv_halo_kernel<%s,\d+,\d+,\d+,%s,%s,%s>" % (m.group(1), m.group(2), "true" if m.group(3) == "nchw" else "false",
+                                                              "true" if m.group(4) else "false")
     return None
 
 
@@ -476,7 +491,7 @@ def main():
             model.sub_batches = S
             ops.set_trace(None)
             summ = tr.summary()
-            dom = max((k for k in summ if k.startswith("conv_fwd_kernel")), key=lambda k: summ[k]["ms"])
+            dom = max((k for k in summ if k.startswith("conv_")), key=lambda k: summ[k]["ms"])
             d = summ[dom]
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             executed = d["xflops"] / (d["ms"] * 1e-3) / 1e12

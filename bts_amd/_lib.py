@@ -21,7 +21,7 @@ SYMBOLS = (
     "bts_reduc_lpg_fwd_f32", "bts_plan_run",
 )
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ConvDesc(C.Structure):
@@ -64,7 +64,8 @@ def source_hash() -> str:
     import glob
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))
+                   + glob.glob(os.path.join(_HERE, "csrc", "*.inc")))
     files.append(os.path.join(os.path.dirname(_HERE), "include", "bts_hip.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -149,7 +150,7 @@ def load_real():
     lib.bts_pack_weights_f32.restype = i
     lib.bts_pack_weights_f32.argtypes = [vp, i, l, vp]
     lib.bts_conv_plan_f32.restype = i
-    lib.bts_conv_plan_f32.argtypes = [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.bts_conv_plan_f32.argtypes = [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.bts_nchw_to_nhwc_f32.restype = i
     lib.bts_nchw_to_nhwc_f32.argtypes = [vp, i, i, l, vp, l, i, vp]
     lib.bts_nhwc_to_nchw_f32.restype = i

@@ -570,6 +570,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
         }
 }
 
+// bts_conv_plan_f32 runs the real dispatch with this set: launch_* then report their choice instead of launching
+struct ConvChoice { int kind, bm, bn, ksplit; };
+thread_local ConvChoice* g_dry = nullptr;
+
 #include "conv_halo.inc"
 
 // Second pass of a split-K convolution: out = E(sum_s ws[s][m][n]) in a FIXED order (deterministic), then the
@@ -632,6 +636,7 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     }
     const long nwg = tiles * a.ksplit;
     if (nwg > 0x7fffffffL) return BTS_ERR_INVALID;
+    if (g_dry) { *g_dry = ConvChoice{0, BM, BN, a.ksplit}; return 0; }
     size_t lds = PREC == 0 ? (size_t)2 * (BM + BN) * LdsLd<MF>::value * sizeof(float)
                            : (size_t)(PREC == 2 ? 1 : 2) * 3 * (BM + BN) * EMU_ROW_BYTES;
     if ((size_t)knobs().lds_bytes > lds && knobs().lds_bytes <= 160 * 1024) lds = (size_t)knobs().lds_bytes;
@@ -686,7 +691,14 @@ void choose_tile(long M, int c_out, int* bm, int* bn) {
 
 }  // namespace
 
-extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
+namespace {
+int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream);
+}
+
+extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) { return conv_dispatch(d, stream); }
+
+namespace {
+int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
     if (!d || !d->x || !d->w || !d->y) return BTS_ERR_INVALID;
     if (d->B <= 0 || d->h_in <= 0 || d->w_in <= 0 || d->c_out <= 0) return BTS_ERR_INVALID;
     if (d->up != 1 && d->up != 2) return BTS_ERR_UNSUPPORTED;
@@ -824,12 +836,14 @@ extern "C" int bts_conv_fwd_f32(const bts_conv_desc* d, bts_stream_t stream) {
     return launch_conv<128, 32, 4, 1>(a, nchw, s, wsf);
 }
 
-extern "C" int bts_conv_plan_f32(const bts_conv_desc* d, int* bm, int* bn) {
-    if (!d || !bm || !bn) return BTS_ERR_INVALID;
-    const int Hs = d->h_in * d->up, Ws = d->w_in * d->up;
-    long H = (Hs + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
-    long W = (Ws + 2 * d->pad - d->dil * (d->ksize - 1) - 1) / d->stride + 1;
-    if (d->subpixel) { H = 2L * d->h_in; W = 2L * d->w_in; }
-    choose_tile((long)d->B * H * W * (d->n_bundles > 1 ? d->n_bundles : 1), d->c_out, bm, bn);
-    return 0;
+}  // namespace
+
+extern "C" int bts_conv_plan_f32(const bts_conv_desc* d, int* bm, int* bn, int* kind) {
+    if (!d || !bm || !bn || !kind) return BTS_ERR_INVALID;
+    ConvChoice c{0, 0, 0, 1};
+    g_dry = &c;
+    const int rc = conv_dispatch(d, nullptr);          // the real decision path; launch_* fill `c` instead of launching
+    g_dry = nullptr;
+    *bm = c.bm; *bn = c.bn; *kind = c.kind + (c.ksplit > 1 ? 16 : 0);
+    return rc;
 }

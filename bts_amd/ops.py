@@ -518,9 +518,13 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     nbytes = 4.0 * (B * h_in * w_in * cin + npix_out * c_out + flops_taps * c_out * cin)
     variant = "conv"
     if _trace is not None:
-        bm, bn = C.c_int(0), C.c_int(0)
-        _lib.load().bts_conv_plan_f32(C.byref(d), C.byref(bm), C.byref(bn))
-        variant = "conv_fwd_kernel<%d,%d,%s>" % (bm.value, bn.value, "nchw" if y_nchw is not None else "nhwc")
+        bm, bn, kind = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.load().bts_conv_plan_f32(C.byref(d), C.byref(bm), C.byref(bn), C.byref(kind))
+        lay = "nchw" if y_nchw is not None else "nhwc"
+        if kind.value & 15:
+            variant = "conv_halo_kernel<%d,k%d,%s%s>" % (bn.value, 2 if subpixel else 3, lay, ",tail" if (kind.value & 15) == 2 else "")
+        else:
+            variant = "conv_fwd_kernel<%d,%d,%s%s>" % (bm.value, bn.value, lay, ",splitk" if kind.value & 16 else "")
     with torch.cuda.device(x2d.device):
         rc = _launch(variant, tag, flops, nbytes, lambda: _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d)),
                      xflops=2.0 * npix_out * c_out * (c_in_ld if n_bundles > 1 else cin) * taps)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 8
+#define BTS_HIP_ABI_VERSION 9
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -185,9 +185,11 @@ typedef struct bts_conv_desc {
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);
 
-/* Which (BM x BN) output tile bts_conv_fwd_f32 will use for this descriptor (host-side query, no GPU
- * work): lets a profiler attribute a launch to its kernel instantiation. */
-int bts_conv_plan_f32(const bts_conv_desc* desc, int* bm, int* bn);
+/* Which kernel bts_conv_fwd_f32 will launch for this descriptor (host-side query, no GPU work: it walks the real
+ * dispatch path): lets a profiler attribute a launch to its kernel instantiation.
+ *   kind & 15: 0 = conv_fwd_kernel (row-tiled, BM x BN), 1 = conv_halo_kernel (spatial 128-pixel tile x BN),
+ *              2 = conv_halo_kernel with the planar tail operand;  kind & 16: split-K (+ splitk_reduce_kernel). */
+int bts_conv_plan_f32(const bts_conv_desc* desc, int* bm, int* bn, int* kind);
 
 /* ------------------------------------------------------------------------------------------
  * Training step (reference: autograd of the nn.Conv2d modules of pytorch/bts.py:70-77, 87-93, 108-119,
