@@ -100,6 +100,9 @@ def trace_to_rocprof_name(kernel):
     m = re.match(r"conv_fwd_kernel<(\d+),(\d+),(nhwc|nchw)(,splitk)?>", kernel)
     if m:
         return r"conv_fwd_kernel<%s,%s,\d+,\d+,\d+,%s(,0)?>" % (m.group(1), m.group(2), "true" if m.group(3) == "nchw" else "false")
+    m = re.match(r"conv1x1_kernel<(\d+)>", kernel)
+    if m:
+        return r"conv1x1_kernel<%s>" % m.group(1)
     m = re.match(r"conv_halo_kernel<(\d+),k(\d),(nhwc|nchw)(,tail)?>", kernel)
     if m:
         return r"conv_halo_kernel<%s,\d+,\d+,\d+,%s,%s,%s>" % (m.group(1), m.group(2), "true" if m.group(3) == "nchw" else "false",

@@ -39,6 +39,7 @@ struct ConvKnobs {
     int no48, force_bm;                                    // BTS_CONV_NO48, BTS_CONV_BM
     int precision, emu_sb;                                 // BTS_CONV_PRECISION, BTS_CONV_EMU_SB (-1 = unset)
     int w8, w8s;                                           // BTS_CONV_W8, BTS_CONV_W8S
+    int k1x1; long k1x1_min_tiles;                         // BTS_CONV_1X1 (1 = wide-tile 1x1 kernel), BTS_CONV_1X1_MIN_TILES
     int halo;                                              // BTS_CONV_HALO: 0 off, 1 = halo-tile kernel where eligible unless split-K applies, 2 = also instead of split-K.  Default 1: on the deep 22x76 maps a frame has only 15 spatial tiles, so at batch 1 split-K fills the chip 7x better (53 vs 16 us per layer), and the choice may not depend on the batch (a frame's bits must not)
 };
 inline long env_long(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
@@ -48,6 +49,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_NO48", 0), (int)env_long("BTS_CONV_BM", 0),
                                 (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
                                 (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1),
+                                (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 100),
                                 (int)env_long("BTS_CONV_HALO", 1)};
     return k;
 }
@@ -575,6 +577,7 @@ struct ConvChoice { int kind, bm, bn, ksplit; };
 thread_local ConvChoice* g_dry = nullptr;
 
 #include "conv_halo.inc"
+#include "conv_1x1.inc"
 
 // Second pass of a split-K convolution: out = E(sum_s ws[s][m][n]) in a FIXED order (deterministic), then the
 // same epilogue / destinations as the fused path.
@@ -802,6 +805,17 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
         if (bn == 128) return bm == 128 ? launch_conv<128, 128, 2, 4, 32, 1>(a, nchw, s, wsf) : launch_conv<64, 128, 2, 4, 32, 1>(a, nchw, s, wsf);
         if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2, 32, 1>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2, 32, 1>(a, nchw, s, wsf);
         return launch_conv<128, 32, 4, 1, 32, 1>(a, nchw, s, wsf);
+    }
+    // plain 1x1 convolutions with a wide output: one workgroup per 128 pixels x 128/192/256 channels (conv_1x1.inc)
+    if (knobs().k1x1 && a.ksize == 1) {
+        const int wide = a.c_out % 192 == 0 ? 192 : (knobs().k1x1 >= 2 ? (a.c_out % 256 == 0 ? 256 : (a.c_out % 128 == 0 ? 128 : 0)) : 0);
+        ConvArgs probe = a;
+        probe.n_ntiles = (a.c_out + bn - 1) / bn;
+        if (wide && !wants_split(probe) && conv1x1_eligible(a, nchw, wide)) {
+            if (wide == 192) return launch_conv1x1<192>(a, s);
+            if (wide == 256) return launch_conv1x1<256>(a, s);
+            return launch_conv1x1<128>(a, s);
+        }
     }
     // stride-1 3x3 (and sub-pixel 2x2) convolutions on maps that tile well: the halo-tile kernel (conv_halo.inc).  The
     // choice depends on per-frame geometry only (never on B), like the split-K decision.

@@ -188,7 +188,8 @@ int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);
 /* Which kernel bts_conv_fwd_f32 will launch for this descriptor (host-side query, no GPU work: it walks the real
  * dispatch path): lets a profiler attribute a launch to its kernel instantiation.
  *   kind & 15: 0 = conv_fwd_kernel (row-tiled, BM x BN), 1 = conv_halo_kernel (spatial 128-pixel tile x BN),
- *              2 = conv_halo_kernel with the planar tail operand;  kind & 16: split-K (+ splitk_reduce_kernel). */
+ *              2 = conv_halo_kernel with the planar tail operand, 3 = conv1x1_kernel (128 pixels x BN);
+ *   kind & 16: split-K (+ splitk_reduce_kernel). */
 int bts_conv_plan_f32(const bts_conv_desc* desc, int* bm, int* bn, int* kind);
 
 /* ------------------------------------------------------------------------------------------

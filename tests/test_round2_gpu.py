@@ -514,3 +514,94 @@ def test_planned_forward_equals_eager_and_follows_weight_changes():
         n(x, None)
         r1 = n(x, None)
         assert all(torch.equal(a, b) for a, b in zip(r0, r1))
+
+
+# --------------------------------------------------------------------------------------------- wide-tile 1x1 kernel
+@pytest.mark.parametrize("cin,cout,shape,pre,e1,res", [(96, 192, (2, 44, 152), True, True, False), (240, 192, (1, 88, 304), True, True, False),
+                                                       (36, 128, (2, 50, 70), False, False, True), (576, 256, (1, 44, 152), True, True, False),
+                                                       (128, 384, (1, 61, 47), False, True, True)])
+def test_conv1x1_wide_tile_vs_torch_and_row_tiled(cin, cout, shape, pre, e1, res):
+    """conv1x1_kernel (128 pixels x 128/192/256 channels per workgroup; DenseNet bottlenecks, ASPP first halves, ResNet
+    bottlenecks) against torch in fp64 -- BN+ReLU prologue, BN/ReLU epilogue, residual, second destination, ragged pixel
+    count, partial last channel chunk -- and bit-for-bit against the row-tiled kernel (same K order by construction)."""
+    import subprocess, sys, json as _json
+    from bts_amd import ops
+    B, h, w = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn((B, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 1, 1), generator=g) * (1.0 / cin ** 0.5)
+    ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    s1, b1 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    r = torch.randn((B, cout, h, w), generator=g)
+    xin = torch.relu(x * ps.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1)) if pre else x
+    ref = torch.nn.functional.conv2d(xin.double(), wt.double())
+    if e1:
+        ref = ref * s1.double().view(1, -1, 1, 1) + b1.double().view(1, -1, 1, 1)
+    if res:
+        ref = ref + r.double()
+    ref = torch.relu(ref)
+    cld = ops.round_up(cin, 4)
+    x2d = torch.zeros((B * h * w, cld))
+    x2d[:, :cin] = x.permute(0, 2, 3, 1).reshape(B * h * w, cin)
+    x2d = x2d.cuda()
+    wp, cop, _ = ops.pack_conv_weight(wt.cuda())
+    kw = dict(act=ops.ACT_RELU)
+    if pre:
+        kw.update(pre=(ops.pad_vec(ps.cuda(), cld, 1.0), ops.pad_vec(pb.cuda(), cld, 0.0)), pre_relu=True)
+    if e1:
+        kw.update(e1=(ops.pad_vec(s1.cuda(), cop, 1.0), ops.pad_vec(b1.cuda(), cop, 0.0)))
+    r2d = r.permute(0, 2, 3, 1).reshape(B * h * w, cout).contiguous().cuda() if res else None
+    y = torch.empty((B * h * w, cout), device="cuda")
+    y2 = torch.empty((B * h * w, cout + 8), device="cuda")
+    tr = ops.KernelTrace()
+    ops.set_trace(tr)
+    ops.conv_forward(x2d, B, h, w, wp, cout, 1, y2d=y, y2_2d=y2[:, 4:4 + cout], res2d=r2d, **kw)
+    ops.set_trace(None)
+    wide = cout % 192 == 0                     # DenseNet-161 bottleneck width; other widths stay on the row-tiled kernel
+    assert list(tr.summary()) == (["conv1x1_kernel<192>"] if wide else ["conv_fwd_kernel<%s>" % list(tr.summary())[0].split("<")[1][:-1]])
+    got = y.cpu().double().reshape(B, h, w, cout).permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 3e-6, err
+    assert torch.equal(y2[:, 4:4 + cout], y)
+    if not wide:
+        return
+    # the same layer on the row-tiled kernel (BTS_CONV_1X1=0 is read once per process: ask a child process)
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_round2_gpu as T; "
+            "torch.save(T._conv1x1_case(%d, %d, %r, %r, %r, %r), sys.argv[1])" % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+                cin, cout, shape, pre, e1, res))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "y.pt")
+        env = dict(os.environ, BTS_CONV_1X1="0")
+        subprocess.check_call([sys.executable, "-c", code, out], env=env)
+        y_row = torch.load(out, weights_only=True)
+    assert torch.equal(y_row, y.cpu()), (y_row - y.cpu()).abs().max().item()
+
+
+def _conv1x1_case(cin, cout, shape, pre, e1, res):
+    """Recomputes test_conv1x1_wide_tile_vs_torch_and_row_tiled's launch in this process (whatever kernel its
+    environment selects) and returns the [npix, cout] result on the CPU."""
+    from bts_amd import ops
+    B, h, w = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn((B, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 1, 1), generator=g) * (1.0 / cin ** 0.5)
+    ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    s1, b1 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    r = torch.randn((B, cout, h, w), generator=g)
+    cld = ops.round_up(cin, 4)
+    x2d = torch.zeros((B * h * w, cld))
+    x2d[:, :cin] = x.permute(0, 2, 3, 1).reshape(B * h * w, cin)
+    x2d = x2d.cuda()
+    wp, cop, _ = ops.pack_conv_weight(wt.cuda())
+    kw = dict(act=ops.ACT_RELU)
+    if pre:
+        kw.update(pre=(ops.pad_vec(ps.cuda(), cld, 1.0), ops.pad_vec(pb.cuda(), cld, 0.0)), pre_relu=True)
+    if e1:
+        kw.update(e1=(ops.pad_vec(s1.cuda(), cop, 1.0), ops.pad_vec(b1.cuda(), cop, 0.0)))
+    r2d = r.permute(0, 2, 3, 1).reshape(B * h * w, cout).contiguous().cuda() if res else None
+    y = torch.empty((B * h * w, cout), device="cuda")
+    ops.conv_forward(x2d, B, h, w, wp, cout, 1, y2d=y, res2d=r2d, **kw)
+    torch.cuda.synchronize()
+    return y.cpu()
