@@ -812,7 +812,7 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
         ConvArgs probe = a;
         probe.n_ntiles = (a.c_out + bn - 1) / bn;
         if (wide && !wants_split(probe) && conv1x1_eligible(a, nchw, wide)) {
-            if (wide == 192) return launch_conv1x1<192>(a, s);
+            if (wide == 192) return knobs().k1x1 == 3 ? launch_conv1x1<192, 2>(a, s) : launch_conv1x1<192>(a, s);
             if (wide == 256) return launch_conv1x1<256>(a, s);
             return launch_conv1x1<128>(a, s);
         }
