@@ -186,7 +186,7 @@ class _ConvFn(torch.autograd.Function):
     """y = conv2d(nearest_up(x, up), w, stride, padding, dilation, groups), bias-free, on libbts_hip.so."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, dilation, up, tag, groups):
+    def forward(ctx, x, weight, stride, padding, dilation, up, tag, groups, act=ops.ACT_NONE):
         ops._need(x, "train.conv2d")
         ops._need(weight, "train.conv2d")
         B, C, h, w = x.shape
@@ -198,9 +198,11 @@ class _ConvFn(torch.autograd.Function):
         H = (h * up + 2 * padding - dilation * (k - 1) - 1) // stride + 1
         W = (w * up + 2 * padding - dilation * (k - 1) - 1) // stride + 1
         y = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+        if act not in (ops.ACT_NONE, ops.ACT_ELU):
+            raise BtsHipError("train.conv2d: only ELU can ride in the epilogue (its derivative is a function of y)")
         if groups > 1:
-            if up != 1 or cout != C:
-                raise BtsHipError("train.conv2d: grouped convolutions need cin == cout and no upsample")
+            if up != 1 or cout != C or act != ops.ACT_NONE:
+                raise BtsHipError("train.conv2d: grouped convolutions need cin == cout, no upsample, no activation")
             cb = WeightPacker.bundle_channels(weight, groups)
             wp = _PACKER.get(weight, cb, WeightPacker.FWD, groups)
             ops.conv_forward(x2d, B, h, w, wp, cb, k, dil=dilation, c_in_ld=cb, y2d=y.view(B * H * W, cout), stride=stride,
@@ -208,18 +210,25 @@ class _ConvFn(torch.autograd.Function):
         else:
             wp = _PACKER.get(weight, c4, WeightPacker.FWD)
             ops.conv_forward(x2d, B, h, w, wp, cout, k, dil=dilation, up=up, c_in_ld=c4, y2d=y.view(B * H * W, cout),
-                             stride=stride, pad=padding, tag=tag + ".fwd", c_in_real=C,
+                             stride=stride, pad=padding, tag=tag + ".fwd", c_in_real=C, act=act,
                              splitk_ws=_splitk_workspace(x.device))
-        ctx.save_for_backward(x2d)
+        out = y.permute(0, 3, 1, 2)           # [B,cout,H,W] channels_last view
+        if act == ops.ACT_ELU:
+            ctx.save_for_backward(x2d, out)   # ELU'(v) = 1 (y > 0) or y + 1: the pre-activation is never stored
+        else:
+            ctx.save_for_backward(x2d)
         ctx.weight = weight                   # the caller's parameter object: the packer tracks it by identity/version
         ctx.geom = (B, C, h, w, c4, cout, k, stride, padding, dilation, up, H, W, tag, groups)
-        return y.permute(0, 3, 1, 2)          # [B,cout,H,W] channels_last view
+        ctx.act = act
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x2d, = ctx.saved_tensors
+        x2d = ctx.saved_tensors[0]
         weight = ctx.weight
         B, C, h, w, c4, cout, k, stride, padding, dilation, up, H, W, tag, groups = ctx.geom
+        if ctx.act == ops.ACT_ELU:
+            grad_out = torch.ops.aten.elu_backward(grad_out, 1.0, 1.0, 1.0, True, ctx.saved_tensors[1])
         dy2d, co4 = _nhwc_rows(grad_out)
         dev = grad_out.device
         dx = dw = None
@@ -264,15 +273,16 @@ class _ConvFn(torch.autograd.Function):
                 g = ops.conv_wgrad(x2d, B, h, w, c4, dy2d, co4, k, dil=dilation, stride=stride, pad=padding, up=up,
                                    ws=_workspace(dev), tag=tag + ".wgrad")
                 dw = g[:cout, :, :C].reshape(cout, k, k, C).permute(0, 3, 1, 2).contiguous()   # OIHW, the layout DDP buckets expect
-        return dx, dw, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, padding: int = 0, dilation: int = 1, stride: int = 1,
-           up: int = 1, tag: str = "conv", groups: int = 1) -> torch.Tensor:
+           up: int = 1, tag: str = "conv", groups: int = 1, act: int = ops.ACT_NONE) -> torch.Tensor:
     """Differentiable bias-free convolution on the HIP kernels; ``up=2`` folds a nearest-2x upsample of ``x`` into
-    the gather (reference upconv, bts.py:90-92); ``groups`` > 1: ResNeXt's grouped 3x3 as channel bundles.
+    the gather (reference upconv, bts.py:90-92); ``groups`` > 1: ResNeXt's grouped 3x3 as channel bundles;
+    ``act=ops.ACT_ELU``: the ELU that follows every decoder convolution (bts.py:93, 183-221) applied in the epilogue.
     Returns a channels_last [B,c_out,H,W] tensor."""
-    return _ConvFn.apply(x, weight, stride, padding, dilation, up, tag, groups)
+    return _ConvFn.apply(x, weight, stride, padding, dilation, up, tag, groups, act)
 
 
 _BN_WS: Dict[Tuple[str, int], torch.Tensor] = {}
@@ -284,6 +294,42 @@ def _bn_workspace(device: torch.device, floats: int) -> torch.Tensor:
     if ws is None or ws.numel() < floats:
         ws = _BN_WS[key] = torch.empty(max(floats, 1 << 20), dtype=torch.float32, device=device)
     return ws
+
+
+_PENDING_COUNTS: Dict[int, torch.Tensor] = {}
+_DEFER_DEPTH = [0]
+
+
+def _count_batch(bn):
+    """``num_batches_tracked += 1`` (nn.BatchNorm2d.forward in train() mode).  Inside an encoder / decoder forward
+    (``_deferred_batch_counts``) the ~175 one-element kernels of a step are collected into one multi-tensor add issued
+    when the forward returns; a norm layer run on its own counts immediately."""
+    t = bn.num_batches_tracked
+    if _DEFER_DEPTH[0] == 0:
+        t.add_(1)
+        return
+    if id(t) in _PENDING_COUNTS:          # the same layer twice in one forward: settle the first count now
+        flush_batch_counts()
+    _PENDING_COUNTS[id(t)] = t
+
+
+def flush_batch_counts():
+    if _PENDING_COUNTS:
+        ts = list(_PENDING_COUNTS.values())
+        _PENDING_COUNTS.clear()
+        with torch.no_grad():
+            torch._foreach_add_(ts, 1)
+
+
+class _deferred_batch_counts:
+    def __enter__(self):
+        _DEFER_DEPTH[0] += 1
+
+    def __exit__(self, *exc):
+        _DEFER_DEPTH[0] -= 1
+        if _DEFER_DEPTH[0] == 0:
+            flush_batch_counts()
+        return False
 
 
 class _BnFn(torch.autograd.Function):
@@ -301,7 +347,7 @@ class _BnFn(torch.autograd.Function):
             x2d, C, None if gamma is None else gamma.detach(), None if beta is None else beta.detach(), bn.eps,
             bn.momentum, bn.running_mean if track else None, bn.running_var if track else None, ws)
         if track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            _count_batch(bn)
         y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
         ops.bn_apply(x2d, C, scale, shift, relu, y.view(npix, C))
         ctx.save_for_backward(x2d, mean, invstd, scale, shift)
@@ -346,7 +392,7 @@ def upconv_forward(m, x):
     """upconv.forward, bts.py:90-94."""
     if m.ratio not in (1, 2):
         raise BtsHipError("upconv: ratio %r not built (1 or 2)" % (m.ratio,))
-    return F.elu(conv2d(x, m.conv.weight, padding=1, up=int(m.ratio), tag="upconv"))
+    return conv2d(x, m.conv.weight, padding=1, up=int(m.ratio), tag="upconv", act=ops.ACT_ELU)
 
 
 def reduction_forward(m, net):
@@ -354,8 +400,10 @@ def reduction_forward(m, net):
     for layer in m.reduc:
         if isinstance(layer, torch.nn.Conv2d):                       # plane_params
             net = conv2d(net, layer.weight, tag="reduc")
+        elif isinstance(layer[1], torch.nn.ELU) and layer[1].alpha == 1.0:
+            net = conv2d(net, layer[0].weight, tag="reduc", act=ops.ACT_ELU)   # inter_*: ELU in the epilogue
         else:
-            net = layer[1](conv2d(net, layer[0].weight, tag="reduc"))   # ELU (inter_*) or Sigmoid (final)
+            net = layer[1](conv2d(net, layer[0].weight, tag="reduc"))   # Sigmoid (final)
     if m.is_final:
         return net
     import math
@@ -367,11 +415,16 @@ def reduction_forward(m, net):
 
 
 def _conv_elu(seq, x, tag):
-    return F.elu(conv2d(x, seq[0].weight, padding=1, tag=tag))
+    return conv2d(x, seq[0].weight, padding=1, tag=tag, act=ops.ACT_ELU)
 
 
 def decoder_forward(dec, features, focal):
     """bts.forward in train() mode (bts.py:223-293): same dataflow as the inference path, as an autograd graph."""
+    with _deferred_batch_counts():
+        return _decoder_forward(dec, features, focal)
+
+
+def _decoder_forward(dec, features, focal):
     begin_step()
     skip0, skip1, skip2, skip3 = features[1], features[2], features[3], features[4]
     md = dec.params.max_depth
@@ -453,7 +506,7 @@ class _DenseBlockFn(torch.autograd.Function):
                              pre=(s2[2], s2[3]), pre_relu=True, y2d=buf[:, Ci:Ci + g], tag="enc.fwd", splitk_ws=sk)
             for bn in (L.norm1, L.norm2):
                 if bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked.add_(1)
+                    _count_batch(bn)
             saved += [t1, torch.stack(s1), torch.stack(s2)]
         ctx.save_for_backward(buf, *saved)
         ctx.block = block
@@ -577,8 +630,9 @@ def densenet_encoder_forward(enc, x):
     begin_step()
     taps = [x]
     cur = x.float().contiguous(memory_format=torch.channels_last)
-    _run_children(list(enc.base_model.named_children()), cur,
-                  tapped=lambda name: any(fragment in name for fragment in enc.feat_names), taps=taps)
+    with _deferred_batch_counts():
+        _run_children(list(enc.base_model.named_children()), cur,
+                      tapped=lambda name: any(fragment in name for fragment in enc.feat_names), taps=taps)
     return taps
 
 
@@ -605,11 +659,12 @@ def resnet_encoder_forward(enc, x):
     m = enc.base_model
     cur = x.float().contiguous(memory_format=torch.channels_last)
     c1 = m.conv1
-    cur = _bn(conv2d(cur, c1.weight, padding=c1.padding[0], stride=c1.stride[0], tag="enc"), m.bn1, relu=True)
-    taps = [x, cur]
-    cur = m.maxpool(cur)
-    for li, layer in enumerate((m.layer1, m.layer2, m.layer3, m.layer4)):
-        for blk in layer:
-            cur = _bottleneck(blk, cur, "enc")
-        taps.append(cur)
+    with _deferred_batch_counts():
+        cur = _bn(conv2d(cur, c1.weight, padding=c1.padding[0], stride=c1.stride[0], tag="enc"), m.bn1, relu=True)
+        taps = [x, cur]
+        cur = m.maxpool(cur)
+        for li, layer in enumerate((m.layer1, m.layer2, m.layer3, m.layer4)):
+            for blk in layer:
+                cur = _bottleneck(blk, cur, "enc")
+            taps.append(cur)
     return taps
