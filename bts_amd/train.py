@@ -54,11 +54,17 @@ def _splitk_workspace(device: torch.device) -> torch.Tensor:
 
 
 def _nhwc_rows(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
-    """[B,C,H,W] (any strides) -> ([B*H*W, C4] contiguous NHWC rows with C padded to a multiple of 4, C4).
-    A channels_last tensor with C % 4 == 0 is viewed, not copied."""
+    """[B,C,H,W] (any strides) -> ([B*H*W, C4] NHWC rows with C padded to a multiple of 4, C4).
+    A channels_last tensor with C % 4 == 0 is viewed, not copied -- and so is a CHANNEL SLICE of one (what autograd hands
+    back for the inputs of a torch.cat, and what a dense block's layers read): the kernels take a pixel stride."""
     B, C, H, W = x.shape
-    rows = x.permute(0, 2, 3, 1)
     c4 = ops.round_up(C, 4)
+    if c4 == C and B * H * W > 0 and x.stride(1) == 1 and W > 1 and H > 1:
+        ct = x.stride(3)
+        if (ct >= C and ct % 4 == 0 and x.stride(2) == W * ct and (B == 1 or x.stride(0) == H * W * ct)
+                and x.data_ptr() % 16 == 0):
+            return x.as_strided((B * H * W, C), (ct, 1)), c4
+    rows = x.permute(0, 2, 3, 1)
     if c4 != C:
         rows = F.pad(rows, (0, c4 - C))
     return rows.contiguous().view(B * H * W, c4), c4
@@ -243,7 +249,8 @@ class _ConvFn(torch.autograd.Function):
                 # adjoint of the stride: the gradient sits on the even positions of a zero map of the input's size, and
                 # the stride-1 adjoint below runs on that (4x the FLOPs of the handful of strided layers, exact)
                 u = torch.zeros((B, Hs, Ws, co4), dtype=torch.float32, device=dev)
-                u[:, 0:2 * H:2, 0:2 * W:2] = dy2d.view(B, H, W, co4)
+                u[:, 0:2 * H:2, 0:2 * W:2] = (dy2d.view(B, H, W, co4) if dy2d.is_contiguous()
+                                              else grad_out.permute(0, 2, 3, 1))      # a strided view has co4 == cout
                 g2d, gh, gw = u.view(B * Hs * Ws, co4), Hs, Ws
             dxu = torch.empty((B, Hs, Ws, C), dtype=torch.float32, device=dev)
             if groups > 1:
@@ -520,7 +527,8 @@ class _DenseBlockFn(torch.autograd.Function):
         layers = list(ctx.block.values())
         npix = B * H * W
         dev = grad_out.device
-        G = grad_out.permute(0, 2, 3, 1).reshape(npix, Ct).contiguous().clone()
+        G = torch.empty((npix, Ct), dtype=torch.float32, device=dev)     # private copy: the walk below accumulates into it
+        G.view(B, H, W, Ct).copy_(grad_out.permute(0, 2, 3, 1))
         d_a2 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
         d_t1 = torch.empty((npix, mid), dtype=torch.float32, device=dev)
         d_a1 = torch.empty((npix, Ct), dtype=torch.float32, device=dev)
