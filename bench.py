@@ -102,7 +102,7 @@ def trace_to_rocprof_name(kernel):
         return r"conv_fwd_kernel<%s,%s,\d+,\d+,\d+,%s(,0)?>" % (m.group(1), m.group(2), "true" if m.group(3) == "nchw" else "false")
     m = re.match(r"conv1x1_kernel<(\d+)>", kernel)
     if m:
-        return r"conv1x1_kernel<%s>" % m.group(1)
+        return r"conv1x1_kernel<%s(,\d+)?>" % m.group(1)
     m = re.match(r"conv_halo_kernel<(\d+),k(\d),(nhwc|nchw)(,tail)?>", kernel)
     if m:
         return r"conv_halo_kernel<%s,\d+,\d+,\d+,%s,%s,%s>" % (m.group(1), m.group(2), "true" if m.group(3) == "nchw" else "false",

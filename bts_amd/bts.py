@@ -30,6 +30,7 @@ from ._lib import BtsHipError
 from . import encoders
 from .encoders import build_base_model
 from .workspace import PackCache, WorkspaceCache, tensor_fingerprint
+from . import workspace as _workspace
 from .plan import PlanCache
 from . import _lib as _lib_mod
 
@@ -571,12 +572,20 @@ class BtsModel(nn.Module):
         # DenseNet: norm5 + ReLU become the prologue of the decoder's first conv; ResNet: layer4 is already ReLU'd
         return dec.forward_nhwc(ws, B, H, W, focal, r["dense"], r["norm5"], r["norm5"] is not None, outs=outs)
 
+    def train(self, mode: bool = True):
+        # a mode switch is where a training loop hands weights over to evaluation (bts_main.py:193-275 evaluates every
+        # eval_freq steps): age every packed copy, whatever way the optimiser wrote the parameters (workspace.py)
+        if mode != self.training:
+            _workspace.invalidate_packs()
+        return super().train(mode)
+
     def forward(self, x, focal):
         if self.training and self.native_encoder and isinstance(x, torch.Tensor) and x.is_cuda:
             # training step: encoder + decoder as one autograd graph on the HIP kernels (bts_amd/train.py)
             enc_fwd = train.resnet_encoder_forward if isinstance(self.encoder.base_model, encoders.ResNet) \
                 else train.densenet_encoder_forward
-            return self.decoder(enc_fwd(self.encoder, x), focal)
+            with train.model_step():
+                return self.decoder(enc_fwd(self.encoder, x), focal)
         if not self._native_ok(x):
             skip_feat = self.encoder(x)
             return self.decoder(skip_feat, focal)

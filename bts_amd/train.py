@@ -165,12 +165,13 @@ class WeightPacker:
             self._launch([e], table, blocks, n_rows)
         return e["dst"]
 
-    def refresh(self):
-        """Re-pack every registered weight whose parameter changed since its last packing, in one launch."""
+    def refresh(self, force: bool = False):
+        """Re-pack every registered weight whose parameter changed since its last packing -- with ``force``: every
+        registered weight -- in one launch."""
         dead = [k for k, e in self.entries.items() if e["wref"]() is None]
         for k in dead:
             del self.entries[k]
-        stale = [e for e in self.entries.values() if e["version"] != e["wref"]()._version]
+        stale = [e for e in self.entries.values() if force or e["version"] != e["wref"]()._version]
         if not stale:
             return
         key = tuple(id(e) for e in stale)
@@ -184,8 +185,33 @@ _PACKER = WeightPacker()
 
 
 def begin_step():
-    """Top of a training forward: bring all packed weights up to date with one launch."""
-    _PACKER.refresh()
+    """Top of a training forward: bring all packed weights up to date with one launch.
+
+    Every registered weight is re-packed, changed or not: ``Tensor._version`` is NOT a reliable change signal in a
+    training loop -- torch's fused optimisers (``AdamW(fused=True)``, ``_fused_adamw_``) rewrite the parameters without
+    bumping it -- and in steady state the optimiser has touched every weight anyway (one 0.5 ms launch per step).  For
+    the same reason a training forward also ages the eval-mode packs and recorded graphs/plans of every model
+    (``workspace.invalidate_packs``): the next eval forward re-packs from the current values."""
+    if _STEP_DEPTH[0] > 0:                 # inside model_step(): the model's forward already did this
+        return
+    from . import workspace
+    workspace.invalidate_packs()
+    _PACKER.refresh(force=True)
+
+
+_STEP_DEPTH = [0]
+
+
+class model_step:
+    """``with train.model_step():`` around a whole-model training forward: one begin_step() for encoder + decoder."""
+
+    def __enter__(self):
+        begin_step()
+        _STEP_DEPTH[0] += 1
+
+    def __exit__(self, *exc):
+        _STEP_DEPTH[0] -= 1
+        return False
 
 
 class _ConvFn(torch.autograd.Function):

@@ -106,7 +106,10 @@ class WorkspaceCache:
 def tensor_fingerprint(module: nn.Module) -> Tuple:
     """Cheap fingerprint of a module's parameters and buffers: changes when load_state_dict / an optimiser step /
     .cuda() / dist.broadcast_module touches them (in-place writes bump ``_version``; writes through ``.data`` do NOT,
-    which is why this package never writes through ``.data`` -- callers that do must call ``invalidate_packs``)."""
+    which is why this package never writes through ``.data`` -- callers that do must call ``invalidate_packs``).
+    torch's FUSED optimisers (``AdamW(fused=True)``) do not bump ``_version`` either: a training forward of this
+    package (train.begin_step) and every ``BtsModel.train()/eval()`` mode switch therefore call ``invalidate_packs``
+    themselves, so a train -> eval hand-over never reuses packs of older values."""
     return tuple((t.data_ptr(), t._version, t.device.index if t.device.type != "cpu" else -1)
                  for t in list(module.parameters()) + list(module.buffers()))
 

@@ -40,7 +40,7 @@ def main():
     write, nw = collect(sys.argv[2], "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) & set(write)):
-        if "conv_" not in k and "reduc" not in k and "lpg" not in k and "pool" not in k and "get_depth" not in k \
+        if "conv" not in k and "reduc" not in k and "lpg" not in k and "pool" not in k and "get_depth" not in k \
                 and "pack_planes" not in k and "nhwc" not in k:
             continue
         f = 2.0 * fetch[k] * 1024 / 1e6 / max(nf[k], 1)          # KB -> MB, x2 gfx950 wide-read correction

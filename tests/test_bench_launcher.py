@@ -71,3 +71,22 @@ def test_uneven_global_batch_is_rejected():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-selftest", "--global-batch", "7"], env=_env(),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "not a multiple" in r.stderr
+
+
+def test_kernel_labels_map_to_rocprof_names():
+    """bench.py matches its own kernel labels to rocprofv3's demangled names (PMC traffic per launch): one pattern
+    per kernel family, checked against names copied from a kernel-stats CSV."""
+    import re
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = ["conv_fwd_kernel<64,128,2,4,32,false,0>", "conv_fwd_kernel<128,48,4,1,16,false,0>",
+            "conv_halo_kernel<32,4,1,32,3,true,true>", "conv_halo_kernel<128,4,2,32,2,false,false>",
+            "conv1x1_kernel<192,4>", "conv1x1_kernel<192,2>"]
+    cases = {"conv_fwd_kernel<64,128,nhwc>": [seen[0]], "conv_fwd_kernel<128,48,nhwc,splitk>": [seen[1]],
+             "conv_halo_kernel<32,k3,nchw,tail>": [seen[2]], "conv_halo_kernel<128,k2,nhwc>": [seen[3]],
+             "conv1x1_kernel<192>": [seen[4], seen[5]]}
+    for label, want in cases.items():
+        pat = bench.trace_to_rocprof_name(label)
+        assert pat is not None, label
+        assert [s for s in seen if re.fullmatch(pat, s)] == want, (label, pat)
+    assert bench.trace_to_rocprof_name("get_depth_kernel<32>") is None

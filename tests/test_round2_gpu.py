@@ -605,3 +605,38 @@ def _conv1x1_case(cin, cout, shape, pre, e1, res):
     ops.conv_forward(x2d, B, h, w, wp, cout, 1, y2d=y, res2d=r2d, **kw)
     torch.cuda.synchronize()
     return y.cpu()
+
+
+# ------------------------------------------------------------------------------------------------ fused optimisers
+def test_fused_adamw_steps_reach_the_kernels_and_the_eval_forward():
+    """torch's fused AdamW rewrites the parameters WITHOUT bumping Tensor._version, the signal the packed-weight caches
+    watch.  A training forward must nevertheless compute with the updated values (train.begin_step re-packs every
+    registered weight) and the eval forward after model.eval() must too (mode switch -> invalidate_packs).  Yardstick:
+    the same steps taken with the multi-tensor (version-bumping) AdamW."""
+    from bts_amd import bts as M, trainer
+    img = t(synth.image_batch(2, 64, 96, 11)).cuda()
+    foc = t(synth.focal_values(2, "kitti", 11)).cuda()
+    gt = (torch.rand(2, 1, 64, 96, generator=torch.Generator().manual_seed(5)) * 60 + 2).cuda()
+    crit = M.silog_loss(0.85)
+    runs = {}
+    for fused in (False, True):
+        m = copy.deepcopy(_model("densenet121_bts", seed=4)).cuda()
+        with torch.no_grad():
+            before = [o.clone() for o in m.eval()(img, foc)]                 # packs the initial weights for eval mode
+        m.train()
+        opt = trainer.make_optimizer(m, 1e-3, 1e-2, 1e-3, fused=fused)
+        losses = []
+        for _ in range(3):
+            loss, _ = trainer.train_step(m, opt, crit, img, foc, gt)
+            losses.append(float(loss.detach()))
+        with torch.no_grad():
+            after = [o.clone() for o in m.eval()(img, foc)]
+        assert not torch.equal(before[4], after[4]), "eval forward still uses the weights packed before training"
+        runs[fused] = (losses, after)
+    (l0, a0), (l1, a1) = runs[False], runs[True]
+    assert abs(l0[0] - l1[0]) <= 1e-6 * abs(l0[0])                           # identical first step
+    assert l1[1] != l1[0] and l1[2] != l1[1], "the loss never moved: stale packed weights in the training forward"
+    for x, y in zip(l0, l1):
+        assert abs(x - y) <= 2e-3 * abs(x), (l0, l1)                         # two implementations of the same update
+    err = (a0[4] - a1[4]).abs().max().item() / a0[4].abs().max().item()
+    assert err < 2e-2, err
