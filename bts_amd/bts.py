@@ -133,12 +133,14 @@ class atrous_conv(nn.Sequential):
                         c_in=seq[1].in_channels)
         return self._packs.get(seq[1].weight.device, build)
 
-    def run_nhwc(self, x2d, B, h, w, mid2d, y2d):
-        """Two launches: [BN]+ReLU -> 1x1 -> BN -> ReLU (mid), then dilated 3x3 into the y2d slice."""
+    def run_nhwc(self, x2d, B, h, w, mid2d, y2d, splitk_ws=None):
+        """Two launches: [BN]+ReLU -> 1x1 -> BN -> ReLU (mid), then dilated 3x3 into the y2d slice.  ``splitk_ws``:
+        scratch that lets the launches split K in single-frame mode (ops.set_fill_frames(1)); at the default setting
+        the H/8 maps fill the chip and never split."""
         p = self.packed()
         ops.conv_forward(x2d, B, h, w, p["w1"], p["c_mid"], 1, c_in_ld=p["c_in"], pre=p["pre"], pre_relu=True,
-                         e1=p["e1"], act=ops.ACT_RELU, y2d=mid2d, tag="aspp")
-        ops.conv_forward(mid2d, B, h, w, p["w2"], p["c_out"], 3, dil=self.dilation, y2d=y2d, tag="aspp")
+                         e1=p["e1"], act=ops.ACT_RELU, y2d=mid2d, tag="aspp", splitk_ws=splitk_ws)
+        ops.conv_forward(mid2d, B, h, w, p["w2"], p["c_out"], 3, dil=self.dilation, y2d=y2d, tag="aspp", splitk_ws=splitk_ws)
 
     def forward(self, x):
         if self.training:
@@ -429,11 +431,11 @@ class bts(nn.Module):
 
         # dense ASPP (bts.py:237-247): each branch reads a prefix of x8 and appends its 128 channels
         q = nf // 4
-        self.daspp_3.run_nhwc(x8[:, o_i4:o_i4 + nf // 2], B, h8, w8, ws["mid"], x8[:, o_d:o_d + q])
-        self.daspp_6.run_nhwc(x8[:, :o_d + q], B, h8, w8, ws["mid"], x8[:, o_d + q:o_d + 2 * q])
-        self.daspp_12.run_nhwc(x8[:, :o_d + 2 * q], B, h8, w8, ws["mid"], x8[:, o_d + 2 * q:o_d + 3 * q])
-        self.daspp_18.run_nhwc(x8[:, :o_d + 3 * q], B, h8, w8, ws["mid"], x8[:, o_d + 3 * q:o_d + 4 * q])
-        self.daspp_24.run_nhwc(x8[:, :o_d + 4 * q], B, h8, w8, ws["mid"], x8[:, o_d + 4 * q:o_d + 5 * q])
+        self.daspp_3.run_nhwc(x8[:, o_i4:o_i4 + nf // 2], B, h8, w8, ws["mid"], x8[:, o_d:o_d + q], ws["splitk"])
+        self.daspp_6.run_nhwc(x8[:, :o_d + q], B, h8, w8, ws["mid"], x8[:, o_d + q:o_d + 2 * q], ws["splitk"])
+        self.daspp_12.run_nhwc(x8[:, :o_d + 2 * q], B, h8, w8, ws["mid"], x8[:, o_d + 2 * q:o_d + 3 * q], ws["splitk"])
+        self.daspp_18.run_nhwc(x8[:, :o_d + 3 * q], B, h8, w8, ws["mid"], x8[:, o_d + 3 * q:o_d + 4 * q], ws["splitk"])
+        self.daspp_24.run_nhwc(x8[:, :o_d + 4 * q], B, h8, w8, ws["mid"], x8[:, o_d + 4 * q:o_d + 5 * q], ws["splitk"])
         conv("daspp_conv", x8[:, o_d:], h8, w8, q, y2d=ws["daspp_feat"])
 
         def am():

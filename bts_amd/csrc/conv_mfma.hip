@@ -40,6 +40,7 @@ struct ConvKnobs {
     int precision, emu_sb;                                 // BTS_CONV_PRECISION, BTS_CONV_EMU_SB (-1 = unset)
     int w8, w8s;                                           // BTS_CONV_W8, BTS_CONV_W8S
     int k1x1; long k1x1_min_tiles;                         // BTS_CONV_1X1 (1 = wide-tile 1x1 kernel), BTS_CONV_1X1_MIN_TILES
+    int fill_frames;                                       // BTS_CONV_FILL_FRAMES: default of bts_conv_desc.fill_frames (8)
     int halo;                                              // BTS_CONV_HALO: 0 off, 1 = halo-tile kernel where eligible unless split-K applies, 2 = also instead of split-K.  Default 1: on the deep 22x76 maps a frame has only 15 spatial tiles, so at batch 1 split-K fills the chip 7x better (53 vs 16 us per layer), and the choice may not depend on the batch (a frame's bits must not)
 };
 inline long env_long(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
@@ -50,6 +51,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
                                 (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1),
                                 (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 100),
+                                (int)(env_long("BTS_CONV_FILL_FRAMES", 8) > 0 ? env_long("BTS_CONV_FILL_FRAMES", 8) : 8),
                                 (int)env_long("BTS_CONV_HALO", 1)};
     return k;
 }
@@ -87,6 +89,7 @@ struct ConvArgs {
     const float* res; long res_pix_stride;   // optional residual added after e1, before the activation (NHWC)
     const float* tail[4];                    // planar tail operand (conv_halo.inc); tail[j] = plane 0 for unused slots
     int n_tail;
+    int fill_frames;                         // frames assumed to share a launch (bts_conv_desc.fill_frames, resolved)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, in
 // must not depend on how many frames share the launch (frames are independent, bts.py:223-293).
 inline bool wants_split(const ConvArgs& a) {
     if (a.n_classes != 1 || a.ws == nullptr || knobs().split_max <= 1) return false;
-    const long tiles64 = ((8L * a.H * a.W + 63) / 64) * a.n_ntiles;
+    const long tiles64 = (((long)a.fill_frames * a.H * a.W + 63) / 64) * a.n_ntiles;
     return tiles64 < knobs().split_below;
 }
 
@@ -744,7 +747,7 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     a.ksplit = 1; a.its_per_split = nit_all; a.ws_ld = (a.c_out + 3) & ~3;
     const int split_max = knobs().split_max;
     if (wants_split(a)) {
-        const long tiles64 = ((8L * a.H * a.W + 63) / 64) * a.n_ntiles;     // 64-row tiles of a nominal 8-frame launch
+        const long tiles64 = (((long)a.fill_frames * a.H * a.W + 63) / 64) * a.n_ntiles;     // 64-row tiles of a nominal launch
         long sp = knobs().split_target / tiles64;
         if (sp > split_max) sp = split_max;
         if (sp > nit_all / 4) sp = nit_all / 4;
@@ -866,6 +869,8 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
     a.n_classes = a.subpix ? 4 : 1; a.bundled = 0;
     a.res = d->res; a.res_pix_stride = d->res_pix_stride;
     a.n_tail = d->n_tail;
+    if (d->fill_frames < 0 || d->fill_frames > 4096) return BTS_ERR_INVALID;
+    a.fill_frames = d->fill_frames > 0 ? d->fill_frames : knobs().fill_frames;
     for (int j = 0; j < 4; ++j) a.tail[j] = d->n_tail > 0 ? d->tail_planes[j < d->n_tail ? j : 0] : nullptr;
     if (d->n_tail < 0 || d->n_tail > 4) return BTS_ERR_INVALID;
     if (d->n_tail > 0) {

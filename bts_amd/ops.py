@@ -392,6 +392,27 @@ def bn_affine(weight, bias, mean, var, eps: float):
 _conv_precision = 0
 
 
+# bts_conv_desc.fill_frames of every conv_forward call: how many frames the caller expects to share a launch (0 = the
+# library default, 8).  set_fill_frames(1) is the single-frame setting of the reference's test loop.
+_fill_frames = 0
+
+
+def set_fill_frames(n: int) -> int:
+    """Frames per launch the split-K / tile choices are sized for (bts_conv_desc.fill_frames): 0 = default (8: batched
+    throughput), 1 = single-frame latency (bts_test.py's loop: 8.8 -> 6.4 ms of GPU time per 352x1216 frame).  The
+    choice never follows the actual batch (a frame's bits must not depend on its neighbours); results of two settings
+    differ by fp32 summation order.  Recorded plans / graphs are aged.  Returns the previous setting."""
+    global _fill_frames
+    n = int(n)
+    if n < 0 or n > 4096:
+        raise BtsHipError("set_fill_frames: expected 0..4096")
+    prev, _fill_frames = _fill_frames, n
+    if prev != n:
+        from . import workspace
+        workspace.invalidate_packs()
+    return prev
+
+
 def set_conv_precision(mode) -> int:
     """'fp32' / 0 or 'bf16x3' / 1; returns the previous mode."""
     global _conv_precision
@@ -465,6 +486,7 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     keep = []
     d.n_bundles = n_bundles if n_bundles > 1 else 0
     d.precision = _conv_precision
+    d.fill_frames = _fill_frames
     d.n_tail = n_tail
     for j in range(n_tail):
         d.tail_planes[j] = tail_planes[j].data_ptr()

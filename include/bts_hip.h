@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 9
+#define BTS_HIP_ABI_VERSION 10
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -181,6 +181,13 @@ typedef struct bts_conv_desc {
                                 only needs c_in_ld-4 channels.  3x3, pad 1, stride 1, dil 1, up 1 only (the decoder's
                                 conv3 / conv2 / conv1); computed on the fp32-input MFMA whatever `precision` says.         */
     int   n_tail;              /* 0 = no tail                                                                              */
+    int   fill_frames;         /* 0 = default (8, or $BTS_CONV_FILL_FRAMES).  How many frames the caller expects to share one
+                                launch: the launch-filling choices (whether and how far an under-filled layer splits K,
+                                whether the wide 1x1 tile has enough pixel tiles) are sized for fill_frames x H x W pixels.
+                                They are NEVER derived from B itself -- a frame's bits must not depend on its batch -- so a
+                                caller that runs single frames (the reference's test loop, pytorch/bts_test.py:127-147) says
+                                so here: fill_frames = 1 splits K on many more layers (352x1216, batch 1: 8.8 -> 6.4 ms of GPU
+                                time per frame).  Results of different fill_frames differ in summation order (fp32 rounding) */
 } bts_conv_desc;
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);

@@ -640,3 +640,46 @@ def test_fused_adamw_steps_reach_the_kernels_and_the_eval_forward():
         assert abs(x - y) <= 2e-3 * abs(x), (l0, l1)                         # two implementations of the same update
     err = (a0[4] - a1[4]).abs().max().item() / a0[4].abs().max().item()
     assert err < 2e-2, err
+
+
+# ------------------------------------------------------------------------------------------------ single-frame mode
+def test_fill_frames_1_splits_more_layers_stays_frame_independent_and_close():
+    """ops.set_fill_frames(1) (bts_conv_desc.fill_frames): the launch-filling choices are sized for ONE 352x1216 frame
+    per launch (the reference's test loop) instead of eight.  More layers split K (checked through bts_conv_plan_f32 on
+    the ASPP 3x3, which never splits by default); a frame's bits still do not depend on its batch; and the results stay
+    within fp32 summation noise of the default mode."""
+    from bts_amd import ops
+    m = _model("densenet161_bts").cuda()
+    m.sub_batches = 1
+    H, W = 352, 1216
+    img = t(synth.image_batch(2, H, W, 77)).cuda()
+    foc = t(synth.focal_values(2, "kitti", 77)).cuda()
+    kinds = {}
+    try:
+        with torch.no_grad():
+            ref = [o.clone() for o in m(img, foc)]
+            for ff in (0, 1):
+                prev = ops.set_fill_frames(ff)
+                tr = ops.KernelTrace()
+                ops.set_trace(tr)
+                try:
+                    outs = [o.clone() for o in m(img[0:1], foc[0:1])]
+                finally:
+                    ops.set_trace(None)
+                kinds[ff] = sorted({r[0] for r in tr.records if r[1].startswith("aspp")})
+                if ff == 1:
+                    both = m(img, foc)
+                    for a, b in zip(outs, both):
+                        assert torch.equal(a[0], b[0]), "fill_frames=1: frame 0 depends on its batch"
+                    for a, b in zip(both, ref):
+                        err = (a - b).abs().max().item() / b.abs().max().item()
+                        assert err < 2e-5, err
+                    assert not all(torch.equal(a, b) for a, b in zip(both, ref)), "the setting changed nothing"
+                else:
+                    assert prev == 0
+                    for a, b in zip(outs, ref):
+                        assert torch.equal(a[0], b[0])
+    finally:
+        ops.set_fill_frames(0)
+    assert not any("splitk" in k for k in kinds[0]), kinds
+    assert any("splitk" in k for k in kinds[1]), kinds
