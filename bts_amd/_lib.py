@@ -18,7 +18,7 @@ SYMBOLS = (
     "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32", "bts_maxpool3x3s2_nhwc_f32", "bts_bn_relu_avgpool2_nhwc_f32",
     "bts_conv_wgrad_f32", "bts_bn_train_ws_floats", "bts_bn_train_stats_f32", "bts_bn_apply_nhwc_f32", "bts_bn_train_bwd_f32",
     "bts_pack_weights_blocks", "bts_pack_weights_f32", "bts_eval_ws_doubles", "bts_eval_depth_metrics_f32",
-    "bts_reduc_lpg_fwd_f32", "bts_plan_run",
+    "bts_reduc_lpg_fwd_f32", "bts_plan_run", "bts_upconv_combine_f32",
 )
 
 ABI_VERSION = 10
@@ -163,6 +163,8 @@ def load_real():
     lib.bts_pack_planes_f32.argtypes = [vp, vp, vp, vp, i, l, vp, l, vp]
     lib.bts_get_depth_f32.restype = i
     lib.bts_get_depth_f32.argtypes = [vp, vp, i, i, i, i, f, vp, vp, vp]
+    lib.bts_upconv_combine_f32.restype = i
+    lib.bts_upconv_combine_f32.argtypes = [vp, l, i, i, i, i, vp, vp, i, vp, l, vp]
     lib.bts_eval_ws_doubles.restype = l
     lib.bts_eval_ws_doubles.argtypes = [i, i, i]
     lib.bts_eval_depth_metrics_f32.restype = i

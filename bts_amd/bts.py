@@ -164,14 +164,39 @@ class upconv(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, bias=False)
         self.ratio = ratio
         self._packs = PackCache(self)
+        self._packs_taps = PackCache(self)
 
     def packed(self):
-        """Sub-pixel packing (four 2x2 kernels, ops.pack_upconv_subpixel) for ratio 2, plain 3x3 otherwise."""
+        """ratio 2: ("subpix", four 2x2 kernels, ops.pack_upconv_subpixel) or -- ``self.tap_gemm`` -- ("taps", the nine taps
+        side by side as one 1x1 weight, ops.pack_upconv_taps); plain 3x3 packing otherwise."""
         def build():
+            if self.ratio == 2 and self.tap_gemm:
+                return ("taps",) + ops.pack_upconv_taps(self.conv.weight.detach())
             if self.ratio == 2:
-                return ops.pack_upconv_subpixel(self.conv.weight.detach())
-            return ops.pack_conv_weight(self.conv.weight.detach())
-        return self._packs.get(self.conv.weight.device, build)
+                return ("subpix",) + ops.pack_upconv_subpixel(self.conv.weight.detach())
+            return ("plain",) + ops.pack_conv_weight(self.conv.weight.detach())
+        cache = self._packs_taps if (self.ratio == 2 and self.tap_gemm) else self._packs
+        return cache.get(self.conv.weight.device, build)
+
+    # nearest-2x + 3x3 as ONE 1x1 convolution with the nine taps side by side plus a tap-sum pass (9 tap-products per
+    # source pixel) instead of four 2x2 parity convolutions (16): set by the decoder for upconv5, whose 11x38 x 2208-channel
+    # source map is where the GEMM dominates and the extra pass is small (DESIGN.md section 3)
+    tap_gemm = False
+
+    def run_nhwc(self, x2d, B, h, w, y2d, taps_buf=None, e2=None, pre=None, pre_relu=False, c_in_real=None, splitk_ws=None,
+                 tag="decoder_upconv"):
+        """ELU(conv3x3(nearest2x(x))) [-> e2 affine] from the NHWC view x2d [B*h*w, C] into y2d [B*2h*2w, cout]."""
+        form, wp, n_or_pad, c_in_ld = self.packed()
+        cout = self.conv.out_channels
+        cin = c_in_real if c_in_real is not None else self.conv.in_channels
+        if form == "taps":
+            if taps_buf is None:
+                taps_buf = torch.empty((B * h * w, 9 * cout), dtype=torch.float32, device=x2d.device)
+            ops.conv_forward(x2d, B, h, w, wp, 9 * cout, 1, c_in_ld=c_in_ld, pre=pre, pre_relu=pre_relu, y2d=taps_buf[:, :9 * cout],
+                             tag=tag, c_in_real=cin, splitk_ws=splitk_ws, algo_flops=2.0 * 36 * B * h * w * cout * cin)
+            return ops.upconv_combine(taps_buf, B, h, w, cout, y2d, act=ops.ACT_ELU, e2=e2, tag=tag + "_sum")
+        return ops.conv_forward(x2d, B, h, w, wp, cout, 3, dil=1, up=2, act=ops.ACT_ELU, e2=e2, pre=pre, pre_relu=pre_relu,
+                                y2d=y2d, tag=tag, c_in_real=cin, subpixel=True, splitk_ws=splitk_ws)
 
     def forward(self, x):
         if self.ratio not in (1, 2):
@@ -179,11 +204,13 @@ class upconv(nn.Module):
         if self.training:
             return train.upconv_forward(self, x)
         xin, B, C, h, w = _nhwc_in(x)
-        wp, cop, kp = self.packed()
         cout = self.conv.out_channels
         r = self.ratio
         y2d = torch.empty((B * h * r * w * r, cout), dtype=torch.float32, device=x.device)
-        ops.conv_forward(xin, B, h, w, wp, cout, 3, dil=1, up=r, act=ops.ACT_ELU, y2d=y2d, subpixel=(r == 2))
+        if r == 2:
+            self.run_nhwc(xin, B, h, w, y2d, tag="conv")
+        else:
+            ops.conv_forward(xin, B, h, w, self.packed()[1], cout, 3, dil=1, up=1, act=ops.ACT_ELU, y2d=y2d)
         return ops.nhwc_to_nchw(y2d, B, h * r, w * r)
 
 
@@ -291,6 +318,11 @@ class bts(nn.Module):
         ]
         for name, module in plan:
             setattr(self, name, module)
+        # small, wide maps (11x38 x 2208 -> 512, 22x76 x 512 -> 256): 9 tap-products per source pixel instead of the
+        # sub-pixel form's 16; measured 43.3 -> 42.3 -> 41.9 ms/step.  upconv3 (44x152, 256 -> 128) is neutral: its tap
+        # buffer costs what its GEMM saves; upconv2/1 stay sub-pixel on the halo-tile kernel
+        self.upconv5.tap_gemm = True
+        self.upconv4.tap_gemm = True
         self._packs = PackCache(self)
         self._bufs = WorkspaceCache(max_entries=8)      # per-shape NHWC workspaces; shared with replicas, graph-pinnable
 
@@ -345,6 +377,8 @@ class bts(nn.Module):
         r4 = ops.round_up
         ws = dict(
             f5=z(n32, r4(f[4], 4)),
+            taps5=torch.empty((n32, 9 * nf), dtype=torch.float32, device=device),   # upconv5 as a tap GEMM: nine taps x nf
+            taps4=torch.empty((n16, 9 * (nf // 2)), dtype=torch.float32, device=device),
             cat5=z(n16, r4(nf + f[3], 4)),                       # [upconv5 | skip3]
             iconv5=z(n16, nf),
             x8=z(n8, nf // 2 + f[2] + 5 * (nf // 4) + nf // 2),  # [upconv4 | skip2 | d3 d6 d12 d18 d24 | iconv4]
@@ -419,14 +453,15 @@ class bts(nn.Module):
                                     c_in_real=c_in_real, subpixel=(up == 2), splitk_ws=ws["splitk"], tail_planes=tail)
 
         # H/16 and H/8 trunk (bts.py:226-235)
-        conv(self.upconv5.packed(), dense2d, H // 32, W // 32, nf, y2d=ws["cat5"][:, :nf], up=2, e2=P["bn5"],
-             c_in_real=f[4], pre=dense_pre, pre_relu=dense_relu)
+        sk = ws["splitk"]
+        self.upconv5.run_nhwc(dense2d, B, H // 32, W // 32, ws["cat5"][:, :nf], taps_buf=ws.get("taps5"), e2=P["bn5"],
+                              pre=dense_pre, pre_relu=dense_relu, c_in_real=f[4], splitk_ws=sk)
         conv("conv5", ws["cat5"], h16, w16, nf, y2d=ws["iconv5"], c_in_real=nf + f[3])
         x8 = ws["x8"]
         c_cat4 = nf // 2 + f[2]
         o_d = c_cat4                              # first ASPP output slot
         o_i4 = c_cat4 + 5 * (nf // 4)             # iconv4 slot
-        conv(self.upconv4.packed(), ws["iconv5"], h16, w16, nf // 2, y2d=x8[:, :nf // 2], up=2, e2=P["bn4"])
+        self.upconv4.run_nhwc(ws["iconv5"], B, h16, w16, x8[:, :nf // 2], taps_buf=ws.get("taps4"), e2=P["bn4"], splitk_ws=sk)
         conv("conv4", x8[:, :c_cat4], h8, w8, nf // 2, y2d=x8[:, o_i4:o_i4 + nf // 2], e2=P["bn4_2"])
 
         # dense ASPP (bts.py:237-247): each branch reads a prefix of x8 and appends its 128 channels
@@ -457,7 +492,7 @@ class bts(nn.Module):
         self.lpg8x8.abs_min = a8
 
         # H/4 (bts.py:258-270)
-        conv(self.upconv3.packed(), ws["daspp_feat"], h8, w8, q, y2d=c3[:, :q], up=2, e2=P["bn3"])
+        self.upconv3.run_nhwc(ws["daspp_feat"], B, h8, w8, c3[:, :q], e2=P["bn3"], splitk_ws=sk)
         conv("conv3", c3, h4, w4, q, y2d=ws["iconv3"], c_in_real=q + f[1] + 1, tail=[ws["ds8"]])
         depth_4x4_scaled = out_tensor(1, 1)
         a4 = am()
@@ -466,7 +501,7 @@ class bts(nn.Module):
         self.lpg4x4.abs_min = a4
 
         # H/2 (bts.py:272-283)
-        conv(self.upconv2.packed(), ws["iconv3"], h4, w4, nf // 8, y2d=c2[:, :nf // 8], up=2, e2=P["bn2"])
+        self.upconv2.run_nhwc(ws["iconv3"], B, h4, w4, c2[:, :nf // 8], e2=P["bn2"], splitk_ws=sk)
         conv("conv2", c2, h2, w2, nf // 8, y2d=ws["iconv2"], c_in_real=nf // 8 + f[0] + 1, tail=[ws["ds4"]])
         depth_2x2_scaled = out_tensor(2, 1)
         a2 = am()
@@ -476,7 +511,7 @@ class bts(nn.Module):
         # full resolution (bts.py:285-291)
         c1 = ws["cat1"]
         n16c = nf // 16
-        conv(self.upconv1.packed(), ws["iconv2"], h2, w2, n16c, y2d=c1, up=2)
+        self.upconv1.run_nhwc(ws["iconv2"], B, h2, w2, c1, splitk_ws=sk)
         reduc1x1 = out_tensor(3, 1)
         self.reduc1x1.run_nhwc(c1, reduc1x1, False)
         iconv1 = out_tensor(5, n16c)

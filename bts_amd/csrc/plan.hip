@@ -72,6 +72,12 @@ extern "C" int bts_plan_run(bts_op* ops, int n_ops, const bts_plan_patch* patche
                 rc = bts_get_depth_f32(a.iconv1, a.w, a.B, a.C, a.H, a.W, a.max_depth, a.focal, a.final_depth, stream);
                 break;
             }
+            case BTS_OP_UPCONV_COMBINE: {
+                auto& a = o.u.upconv_combine;
+                rc = bts_upconv_combine_f32(a.taps, a.taps_pix_stride, a.B, a.h, a.w, a.c, a.e2_scale, a.e2_shift, a.act, a.y,
+                                            a.y_pix_stride, stream);
+                break;
+            }
             default: rc = BTS_ERR_INVALID;
         }
         o.failed_code = rc;

@@ -371,6 +371,44 @@ def pack_upconv_subpixel(w: torch.Tensor, c_in_ld: Optional[int] = None) -> Tupl
     return out.contiguous(), cout_pad, c_in_ld
 
 
+def pack_upconv_taps(w: torch.Tensor, c_in_ld: Optional[int] = None) -> Tuple[torch.Tensor, int, int]:
+    """upconv as a TAP GEMM (bts_upconv_combine_f32): the 3x3 kernel [cout, cin, 3, 3] as the weight of ONE 1x1
+    convolution with 9*cout outputs, row t*cout + n = w[n, :, ky, kx] with t = 3*ky + kx.  Returns
+    ([9*cout (padded to 32)][k_pad], 9*cout, c_in_ld); cout must be a multiple of 4."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and cout % 4 == 0
+    if c_in_ld is None:
+        c_in_ld = round_up(cin, 4)
+    rows = 9 * cout
+    out = torch.zeros((round_up(rows, 32), round_up(c_in_ld, 32)), dtype=torch.float32, device=w.device)
+    out[:rows, :cin] = w.float().permute(2, 3, 0, 1).reshape(rows, cin)
+    return out.contiguous(), rows, c_in_ld
+
+
+def upconv_combine(taps2d: torch.Tensor, B: int, h: int, w: int, c: int, y2d: torch.Tensor, act: int = ACT_NONE,
+                   e2: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, tag: str = "decoder_upconv_sum"):
+    """Second stage of the tap-GEMM upconv (bts_upconv_combine_f32): taps2d [B*h*w, >= 9*c] -> y2d [B*2h*2w, c] NHWC view."""
+    ts, tc = _rows2d(taps2d, "upconv_combine")
+    ys, yc = _rows2d(y2d, "upconv_combine")
+    if tc < 9 * c or yc != c or c % 4 or taps2d.shape[0] != B * h * w or y2d.shape[0] != 4 * B * h * w:
+        raise BtsHipError("upconv_combine: views %s / %s do not fit B=%d %dx%d c=%d"
+                          % (tuple(taps2d.shape), tuple(y2d.shape), B, h, w, c))
+    es = eb = None
+    if e2 is not None:
+        es, eb = e2
+        _need(es, "upconv_combine")
+        _need(eb, "upconv_combine")
+        if es.numel() < c or eb.numel() < c:
+            raise BtsHipError("upconv_combine: e2 vectors need %d elements" % c)
+    npx = B * h * w
+    with torch.cuda.device(taps2d.device):
+        rc = _launch("upconv_combine_kernel", tag, 0.0, 4.0 * (9 * npx * c + 4 * npx * c),
+                     lambda: _lib.load().bts_upconv_combine_f32(_ptr(taps2d), ts, B, h, w, c, _ptr(es), _ptr(eb), int(act),
+                                                                _ptr(y2d), ys, _stream(taps2d)))
+    _lib.check(rc, "bts_upconv_combine_f32")
+    return y2d
+
+
 def pad_vec(v: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[torch.Tensor]:
     if v is None:
         return None
@@ -430,8 +468,10 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
                  tag: str = "conv", c_in_real: Optional[int] = None, stride: int = 1, pad: Optional[int] = None,
                  y2_2d: Optional[torch.Tensor] = None, subpixel: bool = False,
                  splitk_ws: Optional[torch.Tensor] = None, res2d: Optional[torch.Tensor] = None, n_bundles: int = 1,
-                 tail_planes: Optional[Sequence[torch.Tensor]] = None):
+                 tail_planes: Optional[Sequence[torch.Tensor]] = None, algo_flops: Optional[float] = None):
     """One fused convolution (see bts_conv_desc in include/bts_hip.h).
+    ``algo_flops``: FLOPs of the reference formulation this launch stands for, when that is not the launch's own count
+    (the tap GEMM of an upconv: 9 tap-products per source pixel for the reference's 36); only used by KernelTrace.
     ``tail_planes``: 1..4 contiguous one-channel maps ([B,1,h_in,w_in] or [B,h_in,w_in]) that supply the LAST input
     channels of the reference's concatenated input (bts.py:260, 274, 287) without ever being copied into the NHWC
     buffer: x2d then holds c_in_ld - 4 channels and w_packed is packed with c_in_ld = (buffer channels) + 4.
@@ -537,6 +577,8 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     if n_bundles > 1:                                      # algorithmic FLOPs of the grouped conv are passed in c_in_real
         c_out = c_out * n_bundles                          # (real input channels per OUTPUT channel = channels per group)
     flops = 2.0 * npix_out * c_out * cin * flops_taps      # algorithmic: the reference's 3x3 on the upsampled map
+    if algo_flops is not None:
+        flops = float(algo_flops)
     nbytes = 4.0 * (B * h_in * w_in * cin + npix_out * c_out + flops_taps * c_out * cin)
     variant = "conv"
     if _trace is not None:

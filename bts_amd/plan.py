@@ -35,6 +35,7 @@ _KINDS = {
     "bts_bn_relu_avgpool2_nhwc_f32": (8, "avgpool"),
     "bts_get_depth_f32": (9, "get_depth"),
     "bts_lpg_fwd_f32": (10, "lpg"),
+    "bts_upconv_combine_f32": (11, "upconv_combine"),
 }
 
 _structs: Dict[str, type] = {}

@@ -192,6 +192,18 @@ typedef struct bts_conv_desc {
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);
 
+/* Tap-sum stage of an upconv (nearest-2x + 3x3 conv + activation + affine, pytorch/bts.py:90-94 and the bn that follows,
+ * :227, 231) computed as a TAP GEMM: first ONE 1x1 convolution of the source map with the nine kernel taps side by side
+ * (bts_conv_fwd_f32, c_out = 9*c, weights [t*c + n][c_in] = w[n][c_in][t], no activation) into `taps`, then this call:
+ *   y[b][2Y+py][2X+px][n] = e2(act( sum_{ky,kx} taps[b][Y+dy(py,ky)][X+dx(px,kx)][(3*ky+kx)*c + n] )),
+ *   dy(0,.) = (-1,0,0), dy(1,.) = (0,0,+1), same for dx; source pixels outside the map contribute 0.
+ * 9 tap-products per source pixel instead of the sub-pixel form's 16 (or the reference's 36): what a small, wide map wants
+ * (upconv5: 11x38, 2208 -> 512).  taps: [B*h*w] pixels of taps_pix_stride >= 9*c floats; y: NHWC [B,2h,2w] with
+ * y_pix_stride >= c; c % 4 == 0; act 0 none / 1 ReLU / 2 ELU; e2_* [c] or both NULL.  Sum order fixed (tap 0..8). */
+int bts_upconv_combine_f32(const float* taps, long taps_pix_stride, int B, int h, int w, int c,
+                           const float* e2_scale, const float* e2_shift, int act, float* y, long y_pix_stride,
+                           bts_stream_t stream);
+
 /* Which kernel bts_conv_fwd_f32 will launch for this descriptor (host-side query, no GPU work: it walks the real
  * dispatch path): lets a profiler attribute a launch to its kernel instantiation.
  *   kind & 15: 0 = conv_fwd_kernel (row-tiled, BM x BN), 1 = conv_halo_kernel (spatial 128-pixel tile x BN),
@@ -350,7 +362,8 @@ int bts_eval_depth_metrics_f32(const float* pred, int B, int Hp, int Wp, const f
  * Returns the first non-zero code of an entry point (the remaining ops are not enqueued), 0 otherwise.
  */
 enum { BTS_OP_CONV = 1, BTS_OP_REDUC = 2, BTS_OP_REDUC_LPG = 3, BTS_OP_LPG_FUSED = 4, BTS_OP_NCHW_TO_NHWC = 5,
-       BTS_OP_NHWC_TO_NCHW = 6, BTS_OP_MAXPOOL = 7, BTS_OP_BN_RELU_AVGPOOL = 8, BTS_OP_GET_DEPTH = 9, BTS_OP_LPG = 10 };
+       BTS_OP_NHWC_TO_NCHW = 6, BTS_OP_MAXPOOL = 7, BTS_OP_BN_RELU_AVGPOOL = 8, BTS_OP_GET_DEPTH = 9, BTS_OP_LPG = 10,
+       BTS_OP_UPCONV_COMBINE = 11 };
 
 typedef struct bts_op {
     int kind;          /* BTS_OP_*                                                              */
@@ -372,6 +385,8 @@ typedef struct bts_op {
                  long dst_pix_stride; } avgpool;
         struct { const float* iconv1; const float* w; int B, C, H, W; float max_depth; const float* focal;
                  float* final_depth; } get_depth;
+        struct { const float* taps; long taps_pix_stride; int B, h, w, c; const float* e2_scale; const float* e2_shift; int act;
+                 float* y; long y_pix_stride; } upconv_combine;
     } u;
 } bts_op;
 

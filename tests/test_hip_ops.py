@@ -321,6 +321,43 @@ def test_upconv_subpixel(ops, cin, cout, shape):
           what="subpixel upconv %d->%d" % (cin, cout))
 
 
+@pytest.mark.parametrize("cin,cout,shape,act", [(64, 32, (2, 9, 14), 2), (2208, 512, (2, 11, 38), 2), (36, 64, (3, 1, 1), 2),
+                                                (48, 256, (1, 11, 2), 1), (128, 128, (1, 5, 7), 0)])
+def test_upconv_tap_gemm(ops, cin, cout, shape, act):
+    """The same upconv + bn as a TAP GEMM: one 1x1 convolution with the nine kernel taps side by side
+    (ops.pack_upconv_taps), then bts_upconv_combine_f32 sums the nine taps each output pixel sees, applies the
+    activation and the affine -- against torch on the CPU and against the sub-pixel form; 1-pixel maps, the real upconv5
+    shape (11x38, 2208 -> 512), strided destination, untouched neighbours."""
+    B, h, w = shape
+    rng = np.random.Generator(np.random.PCG64(cin * 3 + cout))
+    x = rng.standard_normal(size=(B, cin, h, w), dtype=np.float32)
+    wt = (rng.standard_normal(size=(cout, cin, 3, 3)) * 0.05).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, size=cout).astype(np.float32)
+    sh = (rng.standard_normal(size=cout) * 0.1).astype(np.float32)
+    ref = F.conv2d(F.interpolate(torch.from_numpy(x), scale_factor=2, mode="nearest"), torch.from_numpy(wt), padding=1)
+    ref = {0: lambda v: v, 1: F.relu, 2: F.elu}[act](ref)
+    ref = ref * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1)
+    xin = torch.zeros(B * h * w, cin, device="cuda")
+    ops.nchw_to_nhwc(dev(x), xin)
+    wp, rows, cld = ops.pack_upconv_taps(dev(wt))
+    assert rows == 9 * cout and wp.shape[0] % 32 == 0
+    taps = torch.full((B * h * w, 9 * cout + 4), 7.0, device="cuda")
+    ops.conv_forward(xin, B, h, w, wp, 9 * cout, 1, c_in_ld=cld, y2d=taps[:, :9 * cout])
+    e2 = (dev(sc), dev(sh))
+    yb = torch.full((B * 4 * h * w, cout + 4), -3.0, device="cuda")
+    ops.upconv_combine(taps, B, h, w, cout, yb[:, 4:], act=act, e2=e2)
+    assert (yb[:, :4] == -3.0).all() and (taps[:, 9 * cout:] == 7.0).all()
+    got = ops.nhwc_to_nchw(yb[:, 4:], B, 2 * h, 2 * w)
+    close(got, ref, rtol=1e-4, atol=2e-5 * max(1.0, float(ref.abs().max())), what="tap-GEMM upconv %d->%d" % (cin, cout))
+    if act == 2:                                            # the sub-pixel form of the same layer: fp32 summation order only
+        wp4, cop, cld4 = ops.pack_upconv_subpixel(dev(wt))
+        e2p = (dev(ops.pad_vec(torch.from_numpy(sc), cop, 1.0)), dev(ops.pad_vec(torch.from_numpy(sh), cop, 0.0)))
+        y4 = torch.empty((B * 4 * h * w, cout), device="cuda")
+        ops.conv_forward(xin, B, h, w, wp4, cout, 3, up=2, act=ops.ACT_ELU, e2=e2p, y2d=y4, subpixel=True)
+        err = (y4 - yb[:, 4:]).abs().max().item() / max(1.0, float(ref.abs().max()))
+        assert err < 2e-5, err
+
+
 @pytest.mark.parametrize("shape,nchw", [((2, 13, 17), False), ((1, 40, 52), False), ((3, 7, 5), True)])
 def test_conv_growth48_mfma16(ops, shape, nchw):
     """DenseNet dense-layer 3x3 (192 -> 48): runs on the 16x16x4-MFMA tile variant (BN = 48), ragged M,
