@@ -100,9 +100,9 @@ def trace_to_rocprof_name(kernel):
     m = re.match(r"conv_fwd_kernel<(\d+),(\d+),(nhwc|nchw)(,splitk)?>", kernel)
     if m:
         return r"conv_fwd_kernel<%s,%s,\d+,\d+,\d+,%s(,0)?>" % (m.group(1), m.group(2), "true" if m.group(3) == "nchw" else "false")
-    m = re.match(r"conv1x1_kernel<(\d+)>", kernel)
+    m = re.match(r"conv1x1_kernel<(\d+),(\d+)>", kernel)
     if m:
-        return r"conv1x1_kernel<%s(,\d+)?>" % m.group(1)
+        return r"conv1x1_kernel<%s,%s>" % (m.group(1), m.group(2))
     m = re.match(r"conv_halo_kernel<(\d+),k(\d),(nhwc|nchw)(,tail)?>", kernel)
     if m:
         return r"conv_halo_kernel<%s,\d+,\d+,\d+,%s,%s,%s>" % (m.group(1), m.group(2), "true" if m.group(3) == "nchw" else "false",
@@ -494,18 +494,26 @@ def main():
             model.sub_batches = S
             ops.set_trace(None)
             summ = tr.summary()
-            dom = max((k for k in summ if k.startswith("conv_")), key=lambda k: summ[k]["ms"])
+            # the dominant kernel = the hand-written kernel family with the most isolated time per step
+            dom = max((k for k in summ if k.startswith("conv")), key=lambda k: summ[k]["ms"])
             d = summ[dom]
-            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            algorithmic = d["flops"] / (d["ms"] * 1e-3) / 1e12
             executed = d["xflops"] / (d["ms"] * 1e-3) / 1e12
+            # `achieved` / `frac` price the kernel by the FLOPs its own formulation issues to the matrix pipe.  For most
+            # launches that IS the algorithmic count (2*M*c_out*c_in*taps with real channel counts); where the kernel
+            # runs a cheaper exact formulation of the reference's op (sub-pixel upconv: 16 instead of 36 tap-products
+            # per source pixel; tap-GEMM upconv: 9) the reference-formulation rate is reported next to it
+            # (`algorithmic`) and may exceed the MFMA peak -- it is not a roofline position.
+            achieved = min(algorithmic, executed)
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4),
                     "traffic": (pmc_traffic(dom) or {}).get("hbm_bytes_per_launch"),      # HBM bytes per launch (PMC) or null
                     "traffic_unit": "bytes/launch", "traffic_source": pmc_traffic(dom),
                     "executed": round(executed, 2), "executed_frac": round(executed / PEAK_MFMA_F32_TFLOPS, 4),
-                    "note": "achieved = algorithmic FLOP of the reference formulation / HIP-event time of isolated full-batch "
-                            "launches (the timed region overlaps %d sub-batches of the same kernels); executed = FLOP the "
-                            "kernel's own formulation issues (sub-pixel upconv: 4 taps instead of 9)" % S,
+                    "algorithmic": round(algorithmic, 2),
+                    "note": "achieved = FLOP the kernel issues to the MFMA pipe / HIP-event time of isolated full-batch "
+                            "launches (the timed region overlaps %d sub-batches of the same kernels); algorithmic = the same "
+                            "with the FLOP of the reference formulation (upconv as 3x3 on the upsampled map)" % S,
                     "launches_per_step": d["launches"] // nrep,
                     "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                     "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}

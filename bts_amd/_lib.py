@@ -15,13 +15,13 @@ LIB_PATH = os.path.join(_HERE, "libbts_hip.so")
 SYMBOLS = (
     "bts_hip_abi_version", "bts_hip_error_string", "bts_lpg_fwd_f32", "bts_lpg_bwd_f32", "bts_lpg_fused_fwd_f32",
     "bts_reduc_fwd_f32", "bts_conv_fwd_f32", "bts_nchw_to_nhwc_f32", "bts_nhwc_to_nchw_f32",
-    "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32", "bts_maxpool3x3s2_nhwc_f32", "bts_bn_relu_avgpool2_nhwc_f32",
+    "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32", "bts_conv_plan_ksteps_f32", "bts_maxpool3x3s2_nhwc_f32", "bts_bn_relu_avgpool2_nhwc_f32",
     "bts_conv_wgrad_f32", "bts_bn_train_ws_floats", "bts_bn_train_stats_f32", "bts_bn_apply_nhwc_f32", "bts_bn_train_bwd_f32",
     "bts_pack_weights_blocks", "bts_pack_weights_f32", "bts_eval_ws_doubles", "bts_eval_depth_metrics_f32",
     "bts_reduc_lpg_fwd_f32", "bts_plan_run", "bts_upconv_combine_f32",
 )
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class ConvDesc(C.Structure):
@@ -151,6 +151,8 @@ def load_real():
     lib.bts_pack_weights_f32.argtypes = [vp, i, l, vp]
     lib.bts_conv_plan_f32.restype = i
     lib.bts_conv_plan_f32.argtypes = [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.bts_conv_plan_ksteps_f32.restype = i
+    lib.bts_conv_plan_ksteps_f32.argtypes = [C.POINTER(ConvDesc), C.POINTER(C.c_long), C.POINTER(C.c_long)]
     lib.bts_nchw_to_nhwc_f32.restype = i
     lib.bts_nchw_to_nhwc_f32.argtypes = [vp, i, i, l, vp, l, i, vp]
     lib.bts_nhwc_to_nchw_f32.restype = i

@@ -39,7 +39,10 @@ struct ConvKnobs {
     int no48, force_bm;                                    // BTS_CONV_NO48, BTS_CONV_BM
     int precision, emu_sb;                                 // BTS_CONV_PRECISION, BTS_CONV_EMU_SB (-1 = unset)
     int w8, w8s;                                           // BTS_CONV_W8, BTS_CONV_W8S
-    int k1x1; long k1x1_min_tiles;                         // BTS_CONV_1X1 (1 = wide-tile 1x1 kernel), BTS_CONV_1X1_MIN_TILES
+    int k1x1; long k1x1_min_tiles;                         // BTS_CONV_1X1 (0 off, 1 = wide-tile 1x1 kernel for c_out % 192 == 0, 2 = also 256/128 wide), BTS_CONV_1X1_MIN_TILES
+    int k1x1_rows;                                         // BTS_CONV_1X1_ROWS: 0 = by K (default), 64 / 128 force the wide kernel's row tile
+    int tapskip;                                           // BTS_CONV_TAPSKIP: 0 = run every tap of every tile (A/B), default 1
+    long halo_fill;                                        // BTS_CONV_HALO_FILL: declared-launch workgroups from which the halo kernel replaces split-K (100)
     int fill_frames;                                       // BTS_CONV_FILL_FRAMES: default of bts_conv_desc.fill_frames (8)
     int halo;                                              // BTS_CONV_HALO: 0 off, 1 = halo-tile kernel where eligible unless split-K applies, 2 = also instead of split-K.  Default 1: on the deep 22x76 maps a frame has only 15 spatial tiles, so at batch 1 split-K fills the chip 7x better (53 vs 16 us per layer), and the choice may not depend on the batch (a frame's bits must not)
 };
@@ -51,6 +54,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
                                 (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1),
                                 (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 100),
+                                (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_TAPSKIP", 1), env_long("BTS_CONV_HALO_FILL", 100),
                                 (int)(env_long("BTS_CONV_FILL_FRAMES", 8) > 0 ? env_long("BTS_CONV_FILL_FRAMES", 8) : 8),
                                 (int)env_long("BTS_CONV_HALO", 1)};
     return k;
@@ -90,7 +94,38 @@ struct ConvArgs {
     const float* tail[4];                    // planar tail operand (conv_halo.inc); tail[j] = plane 0 for unused slots
     int n_tail;
     int fill_frames;                         // frames assumed to share a launch (bts_conv_desc.fill_frames, resolved)
+    int tapskip;                             // 1: a tile skips the taps that fall outside the map for ALL of its pixels (tile_tapmask)
 };
+
+// Taps of a ksize x ksize convolution that can touch the map for at least one pixel of the row tile [m0, m0 + bm) -- a
+// conservative superset computed from the tile's first and last pixel only (wave-uniform, SALU).  A dilated ASPP branch
+// (bts.py:65-80: dilation 3..24 on a 44x152 map) reads zero padding for a third of its taps over most of the map:
+// with dilation 24 the three taps of kernel row 0 lie above the map for every pixel of rows 0..23.  Such a K-step
+// multiplies an all-zero A tile; skipping it leaves every accumulator bit unchanged (fma(0, w, acc) == acc).
+// Stride 1 only.  Shared by the kernel and by the host-side FLOP accounting (bts_conv_plan_ksteps_f32).
+__host__ __device__ inline unsigned long long tile_tapmask(int H, int W, int Hs, int Ws, int ksize, int dil, int pad_y, int pad_x,
+                                                           long M, long m0, int bm) {
+    const unsigned HW = (unsigned)(H * W);
+    const long mend = m0 + bm < M ? m0 + bm : M;
+    const unsigned mf = (unsigned)m0, ml = (unsigned)(mend - 1);
+    const unsigned b0 = mf / HW, b1 = ml / HW;
+    const unsigned yx0 = mf - b0 * HW, yx1 = ml - b1 * HW;
+    const int y0 = (int)(yx0 / (unsigned)W), y1 = (int)(yx1 / (unsigned)W);
+    const int x0 = (int)yx0 - y0 * W, x1 = (int)yx1 - y1 * W;
+    const bool one_frame = b0 == b1, one_row = one_frame && y0 == y1;
+    const int ylo = one_frame ? y0 : 0, yhi = one_frame ? y1 : H - 1;
+    const int xlo = one_row ? x0 : 0, xhi = one_row ? x1 : W - 1;
+    unsigned long long mask = 0;
+    for (int t = 0; t < ksize * ksize; ++t) {
+        const int ky = t / ksize, kx = t - ky * ksize;
+        const int dy = ky * dil - pad_y, dx = kx * dil - pad_x;
+        // some y in [ylo, yhi] with 0 <= y + dy < Hs, some x in [xlo, xhi] with 0 <= x + dx < Ws
+        const int ya = ylo > -dy ? ylo : -dy, yb = yhi < Hs - 1 - dy ? yhi : Hs - 1 - dy;
+        const int xa = xlo > -dx ? xlo : -dx, xb = xhi < Ws - 1 - dx ? xhi : Ws - 1 - dx;
+        if (ya <= yb && xa <= xb) mask |= 1ull << t;
+    }
+    return mask ? mask : 1ull;                 // never empty: a tile always runs at least one (all-zero) tap
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
@@ -470,7 +505,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     }
 
     const int it0 = split * a.its_per_split;                       // this workgroup's K-step range
-    const int nit = min(a.k_pad / BK - it0, a.its_per_split);
+    // taps this tile runs (lean path, no split-K): see tile_tapmask.  Otherwise every tap.
+    const bool skipping = fastk && a.tapskip != 0;
+    const unsigned long long tapmask = skipping ? tile_tapmask(a.H, a.W, a.Hs, a.Ws, a.ksize, a.dil, pad_y, pad_x, a.M, m0, BM) : ~0ull;
+    const int nit = skipping ? __builtin_popcountll(tapmask) * kchunks : min(a.k_pad / BK - it0, a.its_per_split);
 
     f32x4 ra[PA], rb[PB];
     f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
@@ -493,12 +531,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
     // Prefetch distance 2 with ONE staging register set: during step `it` the registers hold tile it+1 (its loads
     // were issued a full step ago, so they have landed even on an HBM miss): write it to the other LDS buffer,
     // then reuse the registers for the loads of tile it+2, which get a whole step of MFMAs to arrive.
-    int tap = fastk ? it0 / kchunks : 0;          // lean path: (tap, channel chunk) of the K-step being loaded
-    int kc = fastk ? it0 - tap * kchunks : 0;
-    auto issue = [&](int t) {                     // t = local step index; global K-step = it0 + t
+    int tap = fastk ? (skipping ? __builtin_ctzll(tapmask) : it0 / kchunks) : 0;   // lean path: (tap, channel chunk) of the K-step being loaded
+    int kc = fastk && !skipping ? it0 - tap * kchunks : 0;
+    auto issue = [&](int t) {                     // t = local step index; global K-step = tap * kchunks + kc (lean path)
         if (fastk) {
-            if (t > 0 && ++kc == kchunks) { kc = 0; ++tap; }
-            issue_loads_fast<PA, PB>(a, wbase, pad_y, pad_x, it0 + t, tap, kc, fbase, vmask, wrow, ra, rb, ps, pb, okmask, lk);
+            if (t > 0 && ++kc == kchunks) {       // next tap of this tile (tapmask is all ones unless skipping)
+                kc = 0;
+                const unsigned long long rest = tap < 63 ? tapmask >> (tap + 1) : 0ull;
+                tap += rest ? 1 + __builtin_ctzll(rest) : 1;
+            }
+            issue_loads_fast<PA, PB>(a, wbase, pad_y, pad_x, tap * kchunks + kc, tap, kc, fbase, vmask, wrow, ra, rb, ps, pb, okmask, lk);
         } else {
             issue_loads<PA, PB>(a, wbase, pad_y, pad_x, it0 + t, lk, ay, ax, abase, avalid, wrow, ra, rb, ps, pb, okmask);
         }
@@ -692,7 +734,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(const ConvArgs a
 }
 
 // bts_conv_plan_f32 runs the real dispatch with this set: launch_* then report their choice instead of launching
-struct ConvChoice { int kind, bm, bn, ksplit; };
+struct ConvChoice { int kind, bm, bn, ksplit; long ksteps_issued = 0, ksteps_dense = 0; };   // ksteps: tap-steps over all row tiles (tap skipping)
 thread_local ConvChoice* g_dry = nullptr;
 
 #include "conv_halo.inc"
@@ -732,6 +774,20 @@ inline bool wants_split(const ConvArgs& a) {
     return tiles64 < knobs().split_below;
 }
 
+// The split factor launch_conv will use (1 = no split): the one place that decides it, so the dispatch can ask "will this
+// layer really split?" before it picks a kernel family.  a.n_ntiles must be set; ws_floats = the workspace the caller lent.
+inline int split_factor(const ConvArgs& a, long ws_floats) {
+    if (!wants_split(a)) return 1;
+    const int nit_all = a.k_pad / BK;
+    const long tiles64 = (((long)a.fill_frames * a.H * a.W + 63) / 64) * a.n_ntiles;     // 64-row tiles of a nominal launch
+    long sp = knobs().split_target / tiles64;
+    if (sp > knobs().split_max) sp = knobs().split_max;
+    if (sp > nit_all / 4) sp = nit_all / 4;
+    const long ws_ld = (a.c_out + 3) & ~3;
+    if (sp <= 1 || sp * a.M * ws_ld > ws_floats) return 1;
+    return (int)sp;
+}
+
 template <int BM, int BN, int WM, int WN, int MF = 32, int PREC = 0>
 int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     ConvArgs a = a0;
@@ -745,20 +801,30 @@ int launch_conv(const ConvArgs& a0, bool nchw, hipStream_t s, long ws_floats) {
     // bits, must not depend on how many frames share the launch (frames are independent, bts.py:223-293).
     const int nit_all = a.k_pad / BK;
     a.ksplit = 1; a.its_per_split = nit_all; a.ws_ld = (a.c_out + 3) & ~3;
-    const int split_max = knobs().split_max;
-    if (wants_split(a)) {
-        const long tiles64 = (((long)a.fill_frames * a.H * a.W + 63) / 64) * a.n_ntiles;     // 64-row tiles of a nominal launch
-        long sp = knobs().split_target / tiles64;
-        if (sp > split_max) sp = split_max;
-        if (sp > nit_all / 4) sp = nit_all / 4;
-        if (sp > 1 && sp * a.M * a.ws_ld <= ws_floats) {
-            a.its_per_split = (nit_all + (int)sp - 1) / (int)sp;
-            a.ksplit = (nit_all + a.its_per_split - 1) / a.its_per_split;     // no empty splits
-        }
+    if (const int sp = split_factor(a, ws_floats); sp > 1) {
+        a.its_per_split = (nit_all + sp - 1) / sp;
+        a.ksplit = (nit_all + a.its_per_split - 1) / a.its_per_split;     // no empty splits
     }
     const long nwg = tiles * a.ksplit;
     if (nwg > 0x7fffffffL) return BTS_ERR_INVALID;
-    if (g_dry) { *g_dry = ConvChoice{0, BM, BN, a.ksplit}; return 0; }
+    const bool lean = (a.c_in_ld % BK) == 0 && a.ups == 0;
+    a.tapskip = (knobs().tapskip && lean && a.ksplit == 1 && a.stride == 1 && a.ksize > 1 && a.ksize * a.ksize <= 49) ? 1 : 0;
+    if (g_dry) {
+        *g_dry = ConvChoice{0, BM, BN, a.ksplit};
+        const long taps = (long)a.ksize * a.ksize;
+        g_dry->ksteps_dense = n_mtiles * a.n_classes * taps;
+        g_dry->ksteps_issued = g_dry->ksteps_dense;
+        if (a.tapskip) {                           // the kernel's own tile rule, summed over the row tiles (x classes)
+            long issued = 0;
+            for (int cls = 0; cls < a.n_classes; ++cls) {
+                const int pad_y = a.subpix ? 1 - (cls >> 1) : a.pad, pad_x = a.subpix ? 1 - (cls & 1) : a.pad;
+                for (long mt = 0; mt < n_mtiles; ++mt)
+                    issued += __builtin_popcountll(tile_tapmask(a.H, a.W, a.Hs, a.Ws, a.ksize, a.dil, pad_y, pad_x, a.M, mt * BM, BM));
+            }
+            g_dry->ksteps_issued = issued;
+        }
+        return 0;
+    }
     size_t lds = PREC == 0 ? (size_t)2 * (BM + BN) * LdsLd<MF>::value * sizeof(float)
                            : (size_t)(PREC == 2 ? 1 : 2) * 3 * (BM + BN) * EMU_ROW_BYTES;
     if ((size_t)knobs().lds_bytes > lds && knobs().lds_bytes <= 160 * 1024) lds = (size_t)knobs().lds_bytes;
@@ -927,23 +993,38 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
         if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2, 32, 1>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2, 32, 1>(a, nchw, s, wsf);
         return launch_conv<128, 32, 4, 1, 32, 1>(a, nchw, s, wsf);
     }
-    // plain 1x1 convolutions with a wide output: one workgroup per 128 pixels x 128/192/256 channels (conv_1x1.inc)
+    // plain 1x1 convolutions with a wide output: one workgroup per 128 (or 64) pixels x 192 channels (conv_1x1.inc).
+    // Layers that will really split K stay on the row-tiled kernel (split_factor, not the mere tile-count threshold:
+    // DenseNet block 3's bottlenecks sit under the threshold but end up with a split factor of 1).
     if (knobs().k1x1 && a.ksize == 1) {
-        const int wide = a.c_out % 192 == 0 ? 192 : (knobs().k1x1 >= 2 ? (a.c_out % 256 == 0 ? 256 : (a.c_out % 128 == 0 ? 128 : 0)) : 0);
+        const int wide = a.c_out % 192 == 0 ? 192 : (knobs().k1x1 == 2 ? (a.c_out % 256 == 0 ? 256 : (a.c_out % 128 == 0 ? 128 : 0)) : 0);
         ConvArgs probe = a;
         probe.n_ntiles = (a.c_out + bn - 1) / bn;
-        if (wide && !wants_split(probe) && conv1x1_eligible(a, nchw, wide)) {
-            if (wide == 192) return knobs().k1x1 == 3 ? launch_conv1x1<192, 2>(a, s) : launch_conv1x1<192>(a, s);
+        if (wide && split_factor(probe, wsf) <= 1 && conv1x1_eligible(a, nchw, wide)) {
+            if (wide == 192) {
+                // row tile by K (per-layer geometry, never the batch): a short K loop cannot amortise a 128x192 tile's
+                // prologue and 96 KB of output stores with nothing else resident on the CU -- the 64-row four-wave tile
+                // (74 KB of LDS: two workgroups per CU) overlaps them; from ~24 K-steps on the fatter tile's lower
+                // staging-per-MFMA wins (measured at B=16: block 2, K 192..720: 2.62 -> 2.33 ms with 64 rows;
+                // block 3, K 384..2064: 4.86 ms with 128 rows, 5.06 with 64)
+                const int rows = knobs().k1x1_rows ? knobs().k1x1_rows : (a.c_in_ld <= 768 ? 64 : 128);
+                return rows == 64 ? launch_conv1x1<192, 2>(a, s) : launch_conv1x1<192>(a, s);
+            }
             if (wide == 256) return launch_conv1x1<256>(a, s);
             return launch_conv1x1<128>(a, s);
         }
     }
     // stride-1 3x3 (and sub-pixel 2x2) convolutions on maps that tile well: the halo-tile kernel (conv_halo.inc).  The
-    // choice depends on per-frame geometry only (never on B), like the split-K decision.
+    // choice depends on per-frame geometry and the DECLARED frames per launch only (never on B), like the split-K
+    // decision.  Where a layer would split K, the halo kernel still wins once the declared launch brings enough spatial
+    // tiles (DenseNet block 3 at fill_frames 8: 120 workgroups, 83 -> 55 us per layer at B=16); a single-frame caller
+    // (fill_frames 1-2: 15-30 tiles) keeps split-K, which fills the chip 7x better there.
     if (knobs().halo) {
         ConvArgs probe = a;
         probe.n_ntiles = (a.c_out + bn - 1) / bn;
-        if ((knobs().halo >= 2 || !wants_split(probe)) && halo_eligible(a, true, bn == 48 ? 16 : 32, nullptr)) {
+        const int mf = bn == 48 ? 16 : 32;
+        const long halo_wgs = (long)a.fill_frames * ((a.H + 128 / mf - 1) / (128 / mf)) * ((a.W + mf - 1) / mf) * probe.n_ntiles * a.n_classes;
+        if ((knobs().halo >= 2 || split_factor(probe, wsf) <= 1 || halo_wgs >= knobs().halo_fill) && halo_eligible(a, true, mf, nullptr)) {
             if (a.subpix) {
                 if (bn == 128) return launch_halo<128, 4, 2, 32, 2>(a, nchw, s);
                 if (bn == 64) return launch_halo<64, 4, 2, 32, 2>(a, nchw, s);
@@ -980,5 +1061,15 @@ extern "C" int bts_conv_plan_f32(const bts_conv_desc* d, int* bm, int* bn, int* 
     const int rc = conv_dispatch(d, nullptr);          // the real decision path; launch_* fill `c` instead of launching
     g_dry = nullptr;
     *bm = c.bm; *bn = c.bn; *kind = c.kind + (c.ksplit > 1 ? 16 : 0);
+    return rc;
+}
+
+extern "C" int bts_conv_plan_ksteps_f32(const bts_conv_desc* d, long* issued, long* dense) {
+    if (!d || !issued || !dense) return BTS_ERR_INVALID;
+    ConvChoice c{0, 0, 0, 1};
+    g_dry = &c;
+    const int rc = conv_dispatch(d, nullptr);
+    g_dry = nullptr;
+    *issued = c.ksteps_issued; *dense = c.ksteps_dense;      // both 0 for the kernel families that never skip
     return rc;
 }

@@ -586,14 +586,19 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         _lib.load().bts_conv_plan_f32(C.byref(d), C.byref(bm), C.byref(bn), C.byref(kind))
         lay = "nchw" if y_nchw is not None else "nhwc"
         if (kind.value & 15) == 3:
-            variant = "conv1x1_kernel<%d>" % bn.value if bm.value == 128 else "conv1x1_kernel<%d,%d>" % (bm.value, bn.value)
+            variant = "conv1x1_kernel<%d,%d>" % (bn.value, bm.value // 32)      # <BN, WM>: rows = 32 * WM, as rocprofv3 names it
         elif kind.value & 15:
             variant = "conv_halo_kernel<%d,k%d,%s%s>" % (bn.value, 2 if subpixel else 3, lay, ",tail" if (kind.value & 15) == 2 else "")
         else:
             variant = "conv_fwd_kernel<%d,%d,%s%s>" % (bm.value, bn.value, lay, ",splitk" if kind.value & 16 else "")
+    xflops = 2.0 * npix_out * c_out * (c_in_ld if n_bundles > 1 else cin) * taps
+    if _trace is not None:                                 # tap skipping (dilated ASPP branches): FLOPs really issued
+        issued, dense = C.c_long(0), C.c_long(0)
+        _lib.load().bts_conv_plan_ksteps_f32(C.byref(d), C.byref(issued), C.byref(dense))
+        if dense.value > 0:
+            xflops *= issued.value / dense.value
     with torch.cuda.device(x2d.device):
-        rc = _launch(variant, tag, flops, nbytes, lambda: _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d)),
-                     xflops=2.0 * npix_out * c_out * (c_in_ld if n_bundles > 1 else cin) * taps)
+        rc = _launch(variant, tag, flops, nbytes, lambda: _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d)), xflops=xflops)
     _lib.check(rc, "bts_conv_fwd_f32")
     return out
 

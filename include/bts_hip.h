@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 10
+#define BTS_HIP_ABI_VERSION 11
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -210,6 +210,13 @@ int bts_upconv_combine_f32(const float* taps, long taps_pix_stride, int B, int h
  *              2 = conv_halo_kernel with the planar tail operand, 3 = conv1x1_kernel (128 pixels x BN);
  *   kind & 16: split-K (+ splitk_reduce_kernel). */
 int bts_conv_plan_f32(const bts_conv_desc* desc, int* bm, int* bn, int* kind);
+
+/* Tap-steps the launch really issues vs. the dense count (host-side query, no GPU work).  The row-tiled kernel skips,
+ * per 128/64-pixel row tile, the taps that fall into the zero padding for ALL of the tile's pixels (a dilated ASPP
+ * branch, reference pytorch/bts.py:65-80: dilation 24 on a 44-row map leaves 6 of 9 taps for most tiles); the
+ * skipped products are exact zeros, results are unchanged.  issued / dense = the share of the algorithmic FLOPs
+ * the matrix pipe executes; both are 0 for launches that never skip (halo-tile and wide 1x1 kernels). */
+int bts_conv_plan_ksteps_f32(const bts_conv_desc* desc, long* issued, long* dense);
 
 /* ------------------------------------------------------------------------------------------
  * Training step (reference: autograd of the nn.Conv2d modules of pytorch/bts.py:70-77, 87-93, 108-119,

@@ -84,7 +84,7 @@ def test_kernel_labels_map_to_rocprof_names():
             "conv1x1_kernel<192,4>", "conv1x1_kernel<192,2>"]
     cases = {"conv_fwd_kernel<64,128,nhwc>": [seen[0]], "conv_fwd_kernel<128,48,nhwc,splitk>": [seen[1]],
              "conv_halo_kernel<32,k3,nchw,tail>": [seen[2]], "conv_halo_kernel<128,k2,nhwc>": [seen[3]],
-             "conv1x1_kernel<192>": [seen[4], seen[5]]}
+             "conv1x1_kernel<192,4>": [seen[4]], "conv1x1_kernel<192,2>": [seen[5]]}
     for label, want in cases.items():
         pat = bench.trace_to_rocprof_name(label)
         assert pat is not None, label

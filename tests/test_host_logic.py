@@ -206,3 +206,57 @@ def test_plan_op_layout_matches_header(tmp_path):
     py_sizes = [ctypes.sizeof(plan._BtsOp), plan._BtsOp.u.offset, ctypes.sizeof(plan._BtsPatch),
                 ctypes.sizeof(plan._structs["bts_conv_fwd_f32"]), plan._BtsOp.u.offset + getattr(rl, "a14").offset]
     assert c_sizes == py_sizes, (c_sizes, py_sizes)
+
+
+# ------------------------------------------------------------------------------------------ tap skipping (host side)
+def _ksteps(B, h, w, cin, cout, k, dil, pad, fill=0):
+    """issued / dense tap-steps of a conv launch, through the library's host-side query (no GPU work; the pointers are
+    never dereferenced)."""
+    import ctypes as C
+    from bts_amd import _lib
+    d = _lib.ConvDesc()
+    d.x = d.w = d.y = 0x1000
+    d.x_pix_stride = cin
+    d.c_in_ld = cin
+    d.k_pad = (k * k * cin + 31) // 32 * 32
+    d.B, d.h_in, d.w_in, d.up = B, h, w, 1
+    d.ksize, d.dil, d.stride, d.pad = k, dil, 1, pad
+    d.c_out, d.c_out_pad = cout, (cout + 31) // 32 * 32
+    d.y_pix_stride = cout
+    d.fill_frames = fill
+    issued, dense = C.c_long(-1), C.c_long(-1)
+    bm, bn, kind = C.c_int(0), C.c_int(0), C.c_int(0)
+    lib = _lib.load_real()
+    assert lib.bts_conv_plan_f32(C.byref(d), C.byref(bm), C.byref(bn), C.byref(kind)) == 0
+    assert lib.bts_conv_plan_ksteps_f32(C.byref(d), C.byref(issued), C.byref(dense)) == 0
+    return issued.value, dense.value, bm.value, kind.value
+
+
+@pytest.mark.parametrize("B,h,w,dil", [(2, 44, 152, 24), (2, 44, 152, 18), (1, 44, 152, 3), (3, 52, 68, 24), (1, 13, 17, 24), (2, 11, 19, 6)])
+def test_tap_skipping_rule_is_a_superset_of_the_taps_a_tile_needs(B, h, w, dil):
+    """tile_tapmask (conv_mfma.hip) may only drop a tap that lies in the zero padding for EVERY pixel of the row tile
+    (reference: the dilated 3x3 of atrous_conv, bts.py:75-77, padding = dilation).  Brute force over all pixels: the
+    issued count must cover every (tile, tap) pair with at least one in-map read, and stay below the dense count
+    where the dilation exceeds half the map."""
+    issued, dense, bm, kind = _ksteps(B, h, w, 256, 128, 3, dil, dil)
+    assert kind == 0 and bm in (64, 128)                    # row-tiled kernel, no split-K
+    M = B * h * w
+    n_mt = (M + bm - 1) // bm
+    assert dense == n_mt * 9
+    m = np.arange(M)
+    y, x = (m % (h * w)) // w, m % w
+    needed = 0
+    for ky in range(3):
+        for kx in range(3):
+            ok = (y + (ky - 1) * dil >= 0) & (y + (ky - 1) * dil < h) & (x + (kx - 1) * dil >= 0) & (x + (kx - 1) * dil < w)
+            needed += int(np.add.reduceat(ok, np.arange(0, M, bm)).astype(bool).sum())
+    assert needed <= issued <= dense
+    if 2 * dil > h:                                          # e.g. dilation 24 on 44 rows: most tiles lose a kernel row
+        assert issued < 0.8 * dense
+    assert issued - needed <= 0.1 * dense                    # the first/last-pixel rule is close to exact
+
+
+def test_tap_skipping_off_where_it_cannot_apply():
+    """1x1 convolutions and split-K launches report no skipping (issued == dense or both 0)."""
+    issued, dense, _, kind = _ksteps(2, 44, 152, 256, 256, 1, 1, 0)
+    assert issued == dense

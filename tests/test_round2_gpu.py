@@ -519,7 +519,7 @@ def test_planned_forward_equals_eager_and_follows_weight_changes():
 # --------------------------------------------------------------------------------------------- wide-tile 1x1 kernel
 @pytest.mark.parametrize("cin,cout,shape,pre,e1,res", [(96, 192, (2, 44, 152), True, True, False), (240, 192, (1, 88, 304), True, True, False),
                                                        (36, 128, (2, 50, 70), False, False, True), (576, 256, (1, 44, 152), True, True, False),
-                                                       (128, 384, (1, 61, 47), False, True, True)])
+                                                       (128, 384, (1, 61, 47), False, True, True), (832, 192, (1, 44, 152), True, True, False)])
 def test_conv1x1_wide_tile_vs_torch_and_row_tiled(cin, cout, shape, pre, e1, res):
     """conv1x1_kernel (128 pixels x 128/192/256 channels per workgroup; DenseNet bottlenecks, ASPP first halves, ResNet
     bottlenecks) against torch in fp64 -- BN+ReLU prologue, BN/ReLU epilogue, residual, second destination, ragged pixel
@@ -558,7 +558,8 @@ def test_conv1x1_wide_tile_vs_torch_and_row_tiled(cin, cout, shape, pre, e1, res
     ops.conv_forward(x2d, B, h, w, wp, cout, 1, y2d=y, y2_2d=y2[:, 4:4 + cout], res2d=r2d, **kw)
     ops.set_trace(None)
     wide = cout % 192 == 0                     # DenseNet-161 bottleneck width; other widths stay on the row-tiled kernel
-    assert list(tr.summary()) == (["conv1x1_kernel<192>"] if wide else ["conv_fwd_kernel<%s>" % list(tr.summary())[0].split("<")[1][:-1]])
+    # K <= 768: the 64-row four-wave tile (two workgroups per CU); longer K loops: the 128-row eight-wave tile
+    assert list(tr.summary()) == (["conv1x1_kernel<192,%d>" % (2 if cin <= 768 else 4)] if wide else ["conv_fwd_kernel<%s>" % list(tr.summary())[0].split("<")[1][:-1]])
     got = y.cpu().double().reshape(B, h, w, cout).permute(0, 3, 1, 2)
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err <= 3e-6, err
