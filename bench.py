@@ -100,6 +100,9 @@ def trace_to_rocprof_name(kernel):
     m = re.match(r"conv_fwd_kernel<(\d+),(\d+),(nhwc|nchw)(,splitk)?>", kernel)
     if m:
         return r"conv_fwd_kernel<%s,%s,\d+,\d+,\d+,%s(,0)?>" % (m.group(1), m.group(2), "true" if m.group(3) == "nchw" else "false")
+    m = re.match(r"conv_stem_kernel<(\d+)>", kernel)
+    if m:
+        return r"conv_stem_kernel<%s>" % m.group(1)
     m = re.match(r"conv1x1_kernel<(\d+),(\d+)>", kernel)
     if m:
         return r"conv1x1_kernel<%s,%s>" % (m.group(1), m.group(2))
@@ -535,6 +538,10 @@ def main():
                 else:
                     gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9
                     e.update(gbs=round(gbs, 1), frac_hbm=round(gbs / PEAK_HBM_GBS, 4))
+                    if t.startswith("reduc") and g["flops"] > 0:
+                        # the 8x8 / 4x4 chains sit on the MFMA side of the ridge (AI 100 / 41 FLOP/B): both bounds
+                        tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
+                        e.update(achieved_tflops=round(tf, 2), frac_mfma=round(tf / PEAK_MFMA_F32_TFLOPS, 4))
                 groups[t] = e
             roof["groups"] = groups
             kern = {}
@@ -545,6 +552,8 @@ def main():
                     e["executed_tflops"] = round(v["xflops"] / (v["ms"] * 1e-3) / 1e12, 2)
                 else:
                     e["gbs"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
+                    if k.startswith("reduc") and v["flops"] > 0:
+                        e["tflops"] = round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)
                 kern[k] = e
             roof["kernels"] = kern
             conv_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("conv"))

@@ -41,6 +41,7 @@ struct ConvKnobs {
     int w8, w8s;                                           // BTS_CONV_W8, BTS_CONV_W8S
     int k1x1; long k1x1_min_tiles;                         // BTS_CONV_1X1 (0 off, 1 = wide-tile 1x1 kernel for c_out % 192 == 0, 2 = also 256/128 wide), BTS_CONV_1X1_MIN_TILES
     int k1x1_rows;                                         // BTS_CONV_1X1_ROWS: 0 = by K (default), 64 / 128 force the wide kernel's row tile
+    int stem;                                              // BTS_CONV_STEM: 0 = the stem on the generic row-tiled kernel (A/B), default 1
     int tapskip;                                           // BTS_CONV_TAPSKIP: 0 = run every tap of every tile (A/B), default 1
     long halo_fill;                                        // BTS_CONV_HALO_FILL: declared-launch workgroups from which the halo kernel replaces split-K (100)
     int fill_frames;                                       // BTS_CONV_FILL_FRAMES: default of bts_conv_desc.fill_frames (8)
@@ -54,7 +55,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
                                 (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1),
                                 (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 100),
-                                (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_TAPSKIP", 1), env_long("BTS_CONV_HALO_FILL", 100),
+                                (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), env_long("BTS_CONV_HALO_FILL", 100),
                                 (int)(env_long("BTS_CONV_FILL_FRAMES", 8) > 0 ? env_long("BTS_CONV_FILL_FRAMES", 8) : 8),
                                 (int)env_long("BTS_CONV_HALO", 1)};
     return k;
@@ -94,6 +95,7 @@ struct ConvArgs {
     const float* tail[4];                    // planar tail operand (conv_halo.inc); tail[j] = plane 0 for unused slots
     int n_tail;
     int fill_frames;                         // frames assumed to share a launch (bts_conv_desc.fill_frames, resolved)
+    int halo_single_a;                       // halo-tile kernel: one channel chunk, one A buffer (set by launch_halo)
     int tapskip;                             // 1: a tile skips the taps that fall outside the map for ALL of its pixels (tile_tapmask)
 };
 
@@ -739,6 +741,7 @@ thread_local ConvChoice* g_dry = nullptr;
 
 #include "conv_halo.inc"
 #include "conv_1x1.inc"
+#include "conv_stem.inc"
 
 // Second pass of a split-K convolution: out = E(sum_s ws[s][m][n]) in a FIXED order (deterministic), then the
 // same epilogue / destinations as the fused path.
@@ -957,7 +960,7 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
         if ((double)d->n_bundles * d->c_out_pad * (double)d->k_pad >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
         a.n_classes = d->n_bundles; a.bundled = 1;
     } else if (d->n_bundles < 0) return BTS_ERR_INVALID;
-    a.ksplit = 1; a.its_per_split = 0; a.ws_ld = 0;
+    a.ksplit = 1; a.its_per_split = 0; a.ws_ld = 0; a.tapskip = 0; a.halo_single_a = 0;
     a.ws = d->splitk_ws;
     const long wsf = d->splitk_ws ? d->splitk_ws_floats : 0;
     if (d->splitk_ws && (((uintptr_t)d->splitk_ws & 15) || d->splitk_ws_floats < 0)) return BTS_ERR_INVALID;
@@ -993,6 +996,8 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
         if (bn == 64) return bm == 128 ? launch_conv<128, 64, 4, 2, 32, 1>(a, nchw, s, wsf) : launch_conv<64, 64, 2, 2, 32, 1>(a, nchw, s, wsf);
         return launch_conv<128, 32, 4, 1, 32, 1>(a, nchw, s, wsf);
     }
+    // the encoder stem (7x7 / stride 2 on the 3-channel image): its own kernel (conv_stem.inc)
+    if (knobs().stem && stem_eligible(a, nchw, prec)) return a.c_out == 96 ? launch_stem<96>(a, s) : launch_stem<64>(a, s);
     // plain 1x1 convolutions with a wide output: one workgroup per 128 (or 64) pixels x 192 channels (conv_1x1.inc).
     // Layers that will really split K stay on the row-tiled kernel (split_factor, not the mere tile-count threshold:
     // DenseNet block 3's bottlenecks sit under the threshold but end up with a split factor of 1).

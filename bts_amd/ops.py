@@ -585,7 +585,9 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         bm, bn, kind = C.c_int(0), C.c_int(0), C.c_int(0)
         _lib.load().bts_conv_plan_f32(C.byref(d), C.byref(bm), C.byref(bn), C.byref(kind))
         lay = "nchw" if y_nchw is not None else "nhwc"
-        if (kind.value & 15) == 3:
+        if (kind.value & 15) == 4:
+            variant = "conv_stem_kernel<%d>" % bn.value
+        elif (kind.value & 15) == 3:
             variant = "conv1x1_kernel<%d,%d>" % (bn.value, bm.value // 32)      # <BN, WM>: rows = 32 * WM, as rocprofv3 names it
         elif kind.value & 15:
             variant = "conv_halo_kernel<%d,k%d,%s%s>" % (bn.value, 2 if subpixel else 3, lay, ",tail" if (kind.value & 15) == 2 else "")

@@ -684,3 +684,52 @@ def test_fill_frames_1_splits_more_layers_stays_frame_independent_and_close():
         ops.set_fill_frames(0)
     assert not any("splitk" in k for k in kinds[0]), kinds
     assert any("splitk" in k for k in kinds[1]), kinds
+
+
+# --------------------------------------------------------------------------------------------- encoder stem kernel
+@pytest.mark.parametrize("cout,shape", [(96, (2, 64, 96)), (64, (1, 70, 90)), (96, (3, 38, 50)), (96, (1, 352, 1216))])
+def test_stem_kernel_vs_torch(cout, shape):
+    """conv_stem_kernel (7x7 / stride 2 / pad 3 on the 4-channel-padded image, torchvision conv0 + norm0 + relu0, walked by
+    bts.py:327-338) against torch in fp64: whole tiles, ragged right / bottom tiles (output 35x45, 19x25), zero padding
+    on all four borders, both stem widths (DenseNet161: 96, ResNet / DenseNet121: 64), strided destination."""
+    from bts_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(cout + H)
+    x = torch.randn((B, 3, H, W), generator=g)
+    wt = torch.randn((cout, 3, 7, 7), generator=g) * 0.08
+    s1, b1 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), wt.double(), stride=2, padding=3) * s1.double().view(1, -1, 1, 1)
+                     + b1.double().view(1, -1, 1, 1))
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    x2d = torch.zeros((B * H * W, 4))
+    x2d[:, :3] = x.permute(0, 2, 3, 1).reshape(B * H * W, 3)
+    x2d = x2d.cuda()
+    wp, cop, _ = ops.pack_conv_weight(wt.cuda(), c_in_ld=4)
+    ybuf = torch.full((B * Ho * Wo, cout + 64), float("nan"), device="cuda")       # strided slot of a wider concat buffer
+    tr = ops.KernelTrace()
+    ops.set_trace(tr)
+    ops.conv_forward(x2d, B, H, W, wp, cout, 7, stride=2, pad=3, e1=(ops.pad_vec(s1.cuda(), cop, 1.0), ops.pad_vec(b1.cuda(), cop, 0.0)),
+                     act=ops.ACT_RELU, y2d=ybuf[:, 32:32 + cout], c_in_real=3)
+    ops.set_trace(None)
+    assert list(tr.summary()) == ["conv_stem_kernel<%d>" % cout]
+    got = ybuf[:, 32:32 + cout].cpu().double().reshape(B, Ho, Wo, cout).permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 3e-6, err
+    assert torch.isnan(ybuf[:, :32]).all() and torch.isnan(ybuf[:, 32 + cout:]).all()      # nothing outside the slot
+
+
+def test_stem_kernel_frames_are_independent():
+    """A frame's stem output does not depend on its batch (persistent workgroups walk tiles in a batch-dependent
+    order, the arithmetic per tile is fixed)."""
+    from bts_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((5, 64, 96, 4), generator=g)
+    x[..., 3] = 0
+    wt = torch.randn((96, 3, 7, 7), generator=g) * 0.08
+    wp, cop, _ = ops.pack_conv_weight(wt.cuda(), c_in_ld=4)
+    xa = x.reshape(-1, 4).cuda()
+    ya = torch.empty((5 * 32 * 48, 96), device="cuda")
+    ops.conv_forward(xa, 5, 64, 96, wp, 96, 7, stride=2, pad=3, act=ops.ACT_RELU, y2d=ya, c_in_real=3)
+    y1 = torch.empty((32 * 48, 96), device="cuda")
+    ops.conv_forward(x[3].reshape(-1, 4).cuda(), 1, 64, 96, wp, 96, 7, stride=2, pad=3, act=ops.ACT_RELU, y2d=y1, c_in_real=3)
+    assert torch.equal(ya[3 * 32 * 48:4 * 32 * 48], y1)
