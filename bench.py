@@ -234,6 +234,10 @@ def build_parser():
     ap.add_argument("--streams", type=int, default=4,
                     help="run the per-GPU batch as this many concurrent sub-batches on separate HIP streams (one graph): "
                          "frames are independent, so under-filled launches of one sub-batch overlap the other's")
+    ap.add_argument("--fill-frames", type=int, default=0,
+                    help="frames per launch the library's split-K / tile choices are sized for (bts_conv_desc.fill_frames). "
+                         "0 = by the per-GPU batch: min(8, B/2) -- 8 at the headline B=16 (the library default), 4 for the "
+                         "8-frame rank shard of configs[3], where the default costs 14 %%")
     ap.add_argument("--decoder-only", action="store_true", help="time only the decoder hot path on encoder-shaped features")
     ap.add_argument("--encoder-backend", choices=["hip", "aten", "miopen"], default="hip",
                     help="hip: DenseNet encoder on the HIP conv kernel (default); aten: torch encoder on ATen's native "
@@ -396,6 +400,14 @@ def main():
     S = max(1, args.streams)
     while S > 1 and B % S:
         S -= 1
+    # The caller declares how many frames share the chip: the library never derives it from the batch (a frame's bits
+    # must not depend on its neighbours).  Measured best = half the frames in flight (B=16: 8 -> 41.5 ms, 4 -> 42.7;
+    # B=8: 8 -> 25.8 ms, 4 -> 22.2).  $BTS_CONV_FILL_FRAMES (A/B runs) wins when set.
+    fill_frames = args.fill_frames if args.fill_frames > 0 else max(1, min(8, B // 2))
+    if "BTS_CONV_FILL_FRAMES" not in os.environ:
+        ops.set_fill_frames(fill_frames)
+    else:
+        fill_frames = int(os.environ["BTS_CONV_FILL_FRAMES"])
     model = build_model(params, device, seed=0)
     model.native_encoder = args.encoder_backend == "hip"
     model.sub_batches = S
@@ -574,7 +586,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": G, "image": "%dx%d" % (H, W),
                        "parallelism": "dp%d batch-sharded, RCCL weight broadcast once%s" % (
                            world, ", all-gather of 5 depth maps per step" if gather else ""),
-                       "hipgraph": graph is not None, "sub_batch_streams": S, "encoder_backend": args.encoder_backend,
+                       "hipgraph": graph is not None, "sub_batch_streams": S, "fill_frames": fill_frames, "encoder_backend": args.encoder_backend,
                        "weights": "random-init encoder + PCG64(0) synthetic decoder"},
             "roofline": roof,
         }

@@ -687,29 +687,31 @@ def test_fill_frames_1_splits_more_layers_stays_frame_independent_and_close():
 
 
 # --------------------------------------------------------------------------------------------- encoder stem kernel
-@pytest.mark.parametrize("cout,shape", [(96, (2, 64, 96)), (64, (1, 70, 90)), (96, (3, 38, 50)), (96, (1, 352, 1216))])
-def test_stem_kernel_vs_torch(cout, shape):
+@pytest.mark.parametrize("cout,shape,cin", [(96, (2, 64, 96), 3), (64, (1, 70, 90), 3), (96, (3, 38, 50), 3), (96, (1, 352, 1216), 3),
+                                            (96, (2, 38, 50), 4)])
+def test_stem_kernel_vs_torch(cout, shape, cin):
     """conv_stem_kernel (7x7 / stride 2 / pad 3 on the 4-channel-padded image, torchvision conv0 + norm0 + relu0, walked by
     bts.py:327-338) against torch in fp64: whole tiles, ragged right / bottom tiles (output 35x45, 19x25), zero padding
-    on all four borders, both stem widths (DenseNet161: 96, ResNet / DenseNet121: 64), strided destination."""
+    on all four borders, both stem widths (DenseNet161: 96, ResNet / DenseNet121: 64), strided destination.  cin = 4: a
+    caller whose fourth channel is real (the kernel drops that channel's MFMA step only when its weights are all zero)."""
     from bts_amd import ops
     B, H, W = shape
     g = torch.Generator().manual_seed(cout + H)
-    x = torch.randn((B, 3, H, W), generator=g)
-    wt = torch.randn((cout, 3, 7, 7), generator=g) * 0.08
+    x = torch.randn((B, cin, H, W), generator=g)
+    wt = torch.randn((cout, cin, 7, 7), generator=g) * 0.08
     s1, b1 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
     ref = torch.relu(torch.nn.functional.conv2d(x.double(), wt.double(), stride=2, padding=3) * s1.double().view(1, -1, 1, 1)
                      + b1.double().view(1, -1, 1, 1))
     Ho, Wo = ref.shape[2], ref.shape[3]
     x2d = torch.zeros((B * H * W, 4))
-    x2d[:, :3] = x.permute(0, 2, 3, 1).reshape(B * H * W, 3)
+    x2d[:, :cin] = x.permute(0, 2, 3, 1).reshape(B * H * W, cin)
     x2d = x2d.cuda()
     wp, cop, _ = ops.pack_conv_weight(wt.cuda(), c_in_ld=4)
     ybuf = torch.full((B * Ho * Wo, cout + 64), float("nan"), device="cuda")       # strided slot of a wider concat buffer
     tr = ops.KernelTrace()
     ops.set_trace(tr)
     ops.conv_forward(x2d, B, H, W, wp, cout, 7, stride=2, pad=3, e1=(ops.pad_vec(s1.cuda(), cop, 1.0), ops.pad_vec(b1.cuda(), cop, 0.0)),
-                     act=ops.ACT_RELU, y2d=ybuf[:, 32:32 + cout], c_in_real=3)
+                     act=ops.ACT_RELU, y2d=ybuf[:, 32:32 + cout], c_in_real=cin)
     ops.set_trace(None)
     assert list(tr.summary()) == ["conv_stem_kernel<%d>" % cout]
     got = ybuf[:, 32:32 + cout].cpu().double().reshape(B, Ho, Wo, cout).permute(0, 3, 1, 2)
@@ -733,3 +735,51 @@ def test_stem_kernel_frames_are_independent():
     y1 = torch.empty((32 * 48, 96), device="cuda")
     ops.conv_forward(x[3].reshape(-1, 4).cuda(), 1, 64, 96, wp, 96, 7, stride=2, pad=3, act=ops.ACT_RELU, y2d=y1, c_in_real=3)
     assert torch.equal(ya[3 * 32 * 48:4 * 32 * 48], y1)
+
+
+# --------------------------------------------------------------------------------------------- tap skipping (dilated ASPP)
+def _dilated_case(dil, shape):
+    """One dilated 3x3 of an ASPP branch (BN+ReLU prologue, 256 -> 128, padding = dilation; bts.py:72-77) in this
+    process, whatever BTS_CONV_TAPSKIP says; returns ([npix, 128] result on the CPU, executed/dense tap-step ratio)."""
+    from bts_amd import ops
+    B, h, w = shape
+    g = torch.Generator().manual_seed(100 + dil)
+    x = torch.randn((B * h * w, 256), generator=g).cuda()
+    wt = (torch.randn((128, 256, 3, 3), generator=g) * 0.03).cuda()
+    ps, pb = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.1).cuda()
+    wp, cop, _ = ops.pack_conv_weight(wt)
+    y = torch.empty((B * h * w, 128), device="cuda")
+    tr = ops.KernelTrace()
+    ops.set_trace(tr)
+    ops.conv_forward(x, B, h, w, wp, 128, 3, dil=dil, pad=dil, pre=(ps, pb), pre_relu=True, y2d=y)
+    ops.set_trace(None)
+    (k, v), = tr.summary().items()
+    return y.cpu(), v["xflops"] / v["flops"], k
+
+
+@pytest.mark.parametrize("dil,shape", [(24, (2, 44, 152)), (18, (1, 52, 68)), (6, (2, 44, 152)), (24, (1, 13, 17))])
+def test_tap_skipping_leaves_every_bit_unchanged(dil, shape):
+    """Row tiles of a dilated ASPP convolution skip the taps that read only zero padding (tile_tapmask, conv_mfma.hip).
+    Same launch with BTS_CONV_TAPSKIP=0 in a child process (the knob is read once per process): bit-identical output,
+    and the executed share the trace reports matches the host-side query; vs torch in fp64 as well."""
+    import subprocess, sys, tempfile
+    y, ratio, kern = _dilated_case(dil, shape)
+    assert kern.startswith("conv_fwd_kernel<")
+    assert ratio <= 1.0 and (ratio < 0.8 if 2 * dil > shape[1] else True), ratio
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_round2_gpu as T; "
+            "y, r, k = T._dilated_case(%d, %r); assert r == 1.0, r; torch.save(y, sys.argv[1])" % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), dil, shape))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "y.pt")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, BTS_CONV_TAPSKIP="0"))
+        y_dense = torch.load(out, weights_only=True)
+    assert torch.equal(y_dense, y), (y_dense - y).abs().max().item()
+    B, h, w = shape
+    g = torch.Generator().manual_seed(100 + dil)
+    x = torch.randn((B * h * w, 256), generator=g)
+    wt = torch.randn((128, 256, 3, 3), generator=g) * 0.03
+    ps, pb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    xin = torch.relu(x.double() * ps.double() + pb.double()).reshape(B, h, w, 256).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xin, wt.double(), dilation=dil, padding=dil)
+    got = y.double().reshape(B, h, w, 128).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() / ref.abs().max().item() <= 3e-6
