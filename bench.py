@@ -236,8 +236,8 @@ def build_parser():
                          "frames are independent, so under-filled launches of one sub-batch overlap the other's")
     ap.add_argument("--fill-frames", type=int, default=0,
                     help="frames per launch the library's split-K / tile choices are sized for (bts_conv_desc.fill_frames). "
-                         "0 = by the per-GPU batch: min(8, B/2) -- 8 at the headline B=16 (the library default), 4 for the "
-                         "8-frame rank shard of configs[3], where the default costs 14 %%")
+                         "0 = the per-GPU batch, at most 16: the frames that really share the chip (4 sub-batch streams "
+                         "in flight).  The library default (8) is sized for callers that declare nothing")
     ap.add_argument("--decoder-only", action="store_true", help="time only the decoder hot path on encoder-shaped features")
     ap.add_argument("--encoder-backend", choices=["hip", "aten", "miopen"], default="hip",
                     help="hip: DenseNet encoder on the HIP conv kernel (default); aten: torch encoder on ATen's native "
@@ -401,9 +401,9 @@ def main():
     while S > 1 and B % S:
         S -= 1
     # The caller declares how many frames share the chip: the library never derives it from the batch (a frame's bits
-    # must not depend on its neighbours).  Measured best = half the frames in flight (B=16: 8 -> 41.5 ms, 4 -> 42.7;
-    # B=8: 8 -> 25.8 ms, 4 -> 22.2).  $BTS_CONV_FILL_FRAMES (A/B runs) wins when set.
-    fill_frames = args.fill_frames if args.fill_frames > 0 else max(1, min(8, B // 2))
+    # must not depend on its neighbours).  bench.py runs its B frames as S concurrent sub-batches, so B frames are in
+    # flight: it declares B (at most 16).  $BTS_CONV_FILL_FRAMES (A/B runs) wins when set.
+    fill_frames = args.fill_frames if args.fill_frames > 0 else max(1, min(16, B))
     if "BTS_CONV_FILL_FRAMES" not in os.environ:
         ops.set_fill_frames(fill_frames)
     else:

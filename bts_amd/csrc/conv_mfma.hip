@@ -43,7 +43,7 @@ struct ConvKnobs {
     int k1x1_rows;                                         // BTS_CONV_1X1_ROWS: 0 = by K (default), 64 / 128 force the wide kernel's row tile
     int stem;                                              // BTS_CONV_STEM: 0 = the stem on the generic row-tiled kernel (A/B), default 1
     int tapskip;                                           // BTS_CONV_TAPSKIP: 0 = run every tap of every tile (A/B), default 1
-    long halo_fill;                                        // BTS_CONV_HALO_FILL: declared-launch workgroups from which the halo kernel replaces split-K (100)
+    long halo_fill;                                        // BTS_CONV_HALO_FILL: declared-launch workgroups from which the halo kernel replaces split-K (200)
     int fill_frames;                                       // BTS_CONV_FILL_FRAMES: default of bts_conv_desc.fill_frames (8)
     int halo;                                              // BTS_CONV_HALO: 0 off, 1 = halo-tile kernel where eligible unless split-K applies, 2 = also instead of split-K.  Default 1: on the deep 22x76 maps a frame has only 15 spatial tiles, so at batch 1 split-K fills the chip 7x better (53 vs 16 us per layer), and the choice may not depend on the batch (a frame's bits must not)
 };
@@ -54,8 +54,8 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_NO48", 0), (int)env_long("BTS_CONV_BM", 0),
                                 (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
                                 (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1),
-                                (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 100),
-                                (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), env_long("BTS_CONV_HALO_FILL", 100),
+                                (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 150),
+                                (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), env_long("BTS_CONV_HALO_FILL", 200),
                                 (int)(env_long("BTS_CONV_FILL_FRAMES", 8) > 0 ? env_long("BTS_CONV_FILL_FRAMES", 8) : 8),
                                 (int)env_long("BTS_CONV_HALO", 1)};
     return k;
@@ -1022,8 +1022,10 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
     // stride-1 3x3 (and sub-pixel 2x2) convolutions on maps that tile well: the halo-tile kernel (conv_halo.inc).  The
     // choice depends on per-frame geometry and the DECLARED frames per launch only (never on B), like the split-K
     // decision.  Where a layer would split K, the halo kernel still wins once the declared launch brings enough spatial
-    // tiles (DenseNet block 3 at fill_frames 8: 120 workgroups, 83 -> 55 us per layer at B=16); a single-frame caller
-    // (fill_frames 1-2: 15-30 tiles) keeps split-K, which fills the chip 7x better there.
+    // tiles (DenseNet block 3 at fill_frames 16: 240 workgroups, 83 -> 55 us per layer at B=16).  The threshold (200) sits
+    // ABOVE the library's default fill_frames of 8 (120 workgroups) on purpose: a caller that never declares anything and
+    // runs one frame per call (bts_test.py) would get 15 workgroups per launch from it -- split-K fills the chip 7x
+    // better there (whole forward at batch 1: 8.9 ms with split-K, 12.0 ms with the halo / wide-tile choices).
     if (knobs().halo) {
         ConvArgs probe = a;
         probe.n_ntiles = (a.c_out + bn - 1) / bn;

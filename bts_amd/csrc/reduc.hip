@@ -160,14 +160,8 @@ constexpr long chain_frag_float4s() {
     return n;
 }
 
-// Threads per workgroup: a chain whose weight fragments leave room for only ONE workgroup per CU (8x8: 109 KB of LDS)
-// runs 16 waves on those weights instead of 8 -- four waves per SIMD to fill each other's load / ELU / epilogue gaps,
-// and 4096 waves for the 3344 pixel tiles of a B=16 launch (one round instead of two): 97 -> see DESIGN.md section 3.
-template <int C0, int M0>
-constexpr int reduc_threads() { return chain_frag_float4s<C0, M0>() * 16 > 80 * 1024 ? 1024 : 512; }
-
 template <int C0, int M0, bool FINAL, int LPGK = 0>
-__global__ __launch_bounds__((reduc_threads<C0, M0>()), (reduc_threads<C0, M0>() == 1024 ? 1 : 2)) void reduc_fwd_kernel(const float* __restrict__ x, long x_pix_stride,
+__global__ __launch_bounds__(512, 2) void reduc_fwd_kernel(const float* __restrict__ x, long x_pix_stride,
                                                            long npix, const float4* __restrict__ w_frag,
                                                            float max_depth, int normalize,
                                                            float* __restrict__ out, const LpgTail lt) {
@@ -231,10 +225,9 @@ int launch_reduc(const float* x, long stride, long npix, const float* w_frag, lo
     if (hipError_t e = bts_ensure_dynamic_lds((const void*)kern, lds, lds_set); e != hipSuccess) return (int)e;
     const long ntiles = (npix + 31) / 32;
     const int per_cu = lds > 80 * 1024 ? 1 : 2;
-    constexpr int NTHR = reduc_threads<C0, M0>();
-    long blocks = (ntiles + NTHR / 64 - 1) / (NTHR / 64);
+    long blocks = (ntiles + 7) / 8;
     if (blocks > 256L * per_cu) blocks = 256L * per_cu;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHR), lds, s, x, stride, npix,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, x, stride, npix,
                        reinterpret_cast<const float4*>(w_frag), max_depth, normalize, out, lt);
     return (int)hipGetLastError();
 }
