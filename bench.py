@@ -106,10 +106,11 @@ def trace_to_rocprof_name(kernel):
     m = re.match(r"conv1x1_kernel<(\d+),(\d+)>", kernel)
     if m:
         return r"conv1x1_kernel<%s,%s>" % (m.group(1), m.group(2))
-    m = re.match(r"conv_halo_kernel<(\d+),k(\d),(nhwc|nchw)(,tail)?>", kernel)
+    m = re.match(r"conv_halo_kernel<(\d+),k(\d),(nhwc|nchw)(,tail)?(,w8)?>", kernel)
     if m:
-        return r"conv_halo_kernel<%s,\d+,\d+,\d+,%s,%s,%s>" % (m.group(1), m.group(2), "true" if m.group(3) == "nchw" else "false",
-                                                              "true" if m.group(4) else "false")
+        wm = "8" if m.group(5) else (r"\d+" if m.group(1) != "48" else "4")      # the 48-wide tile has a 4- and an 8-wave variant
+        return r"conv_halo_kernel<%s,%s,\d+,\d+,%s,%s,%s>" % (m.group(1), wm, m.group(2), "true" if m.group(3) == "nchw" else "false",
+                                                            "true" if m.group(4) else "false")
     return None
 
 

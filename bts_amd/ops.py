@@ -590,7 +590,8 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         elif (kind.value & 15) == 3:
             variant = "conv1x1_kernel<%d,%d>" % (bn.value, bm.value // 32)      # <BN, WM>: rows = 32 * WM, as rocprofv3 names it
         elif kind.value & 15:
-            variant = "conv_halo_kernel<%d,k%d,%s%s>" % (bn.value, 2 if subpixel else 3, lay, ",tail" if (kind.value & 15) == 2 else "")
+            variant = "conv_halo_kernel<%d,k%d,%s%s%s>" % (bn.value, 2 if subpixel else 3, lay, ",tail" if (kind.value & 15) == 2 else "",
+                                                          ",w8" if kind.value & 32 else "")
         else:
             variant = "conv_fwd_kernel<%d,%d,%s%s>" % (bm.value, bn.value, lay, ",splitk" if kind.value & 16 else "")
     xflops = 2.0 * npix_out * c_out * (c_in_ld if n_bundles > 1 else cin) * taps

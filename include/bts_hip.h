@@ -209,7 +209,7 @@ int bts_upconv_combine_f32(const float* taps, long taps_pix_stride, int B, int h
  *   kind & 15: 0 = conv_fwd_kernel (row-tiled, BM x BN), 1 = conv_halo_kernel (spatial 128-pixel tile x BN),
  *              2 = conv_halo_kernel with the planar tail operand, 3 = conv1x1_kernel (bm = 128 or 64 pixels x BN),
  *              4 = conv_stem_kernel (7x7 / stride-2 encoder stem, 8x32-pixel tiles x BN);
- *   kind & 16: split-K (+ splitk_reduce_kernel). */
+ *   kind & 16: split-K (+ splitk_reduce_kernel);  kind & 32: the eight-wave variant of the 48-wide halo tile (under-filled launches). */
 int bts_conv_plan_f32(const bts_conv_desc* desc, int* bm, int* bn, int* kind);
 
 /* Tap-steps the launch really issues vs. the dense count (host-side query, no GPU work).  The row-tiled kernel skips,
