@@ -105,7 +105,7 @@ def trace_to_rocprof_name(kernel):
         return r"conv_stem_kernel<%s>" % m.group(1)
     m = re.match(r"conv1x1_kernel<(\d+),(\d+)>", kernel)
     if m:
-        return r"conv1x1_kernel<%s,%s>" % (m.group(1), m.group(2))
+        return r"conv1x1_kernel<%s,%s(,true|,false)?>" % (m.group(1), m.group(2))      # 3rd parameter: single weight buffer
     m = re.match(r"conv_halo_kernel<(\d+),k(\d),(nhwc|nchw)(,tail)?(,w8)?>", kernel)
     if m:
         wm = "8" if m.group(5) else (r"\d+" if m.group(1) != "48" else "4")      # the 48-wide tile has a 4- and an 8-wave variant

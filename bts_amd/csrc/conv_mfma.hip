@@ -40,6 +40,7 @@ struct ConvKnobs {
     int precision, emu_sb;                                 // BTS_CONV_PRECISION, BTS_CONV_EMU_SB (-1 = unset)
     int w8, w8s;                                           // BTS_CONV_W8, BTS_CONV_W8S
     int k1x1; long k1x1_min_tiles;                         // BTS_CONV_1X1 (0 off, 1 = wide-tile 1x1 kernel for c_out % 192 == 0, 2 = also 256/128 wide), BTS_CONV_1X1_MIN_TILES
+    int k1x1_sb;                                           // BTS_CONV_1X1_SB: 1 (default) = the 64-row wide tile keeps one weight buffer (three workgroups per CU), 0 = two
     int k1x1_rows;                                         // BTS_CONV_1X1_ROWS: 0 = by K (default), 64 / 128 force the wide kernel's row tile
     int stem;                                              // BTS_CONV_STEM: 0 = the stem on the generic row-tiled kernel (A/B), default 1
     int tapskip;                                           // BTS_CONV_TAPSKIP: 0 = run every tap of every tile (A/B), default 1
@@ -56,7 +57,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
                                 (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1),
                                 (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 150),
-                                (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), (int)env_long("BTS_CONV_HALO48_W8", 1), env_long("BTS_CONV_HALO48_W8_BELOW", 512), env_long("BTS_CONV_HALO_FILL", 200),
+                                (int)env_long("BTS_CONV_1X1_SB", 1), (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), (int)env_long("BTS_CONV_HALO48_W8", 1), env_long("BTS_CONV_HALO48_W8_BELOW", 512), env_long("BTS_CONV_HALO_FILL", 200),
                                 (int)(env_long("BTS_CONV_FILL_FRAMES", 8) > 0 ? env_long("BTS_CONV_FILL_FRAMES", 8) : 8),
                                 (int)env_long("BTS_CONV_HALO", 1)};
     return k;
@@ -1014,7 +1015,8 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
                 // staging-per-MFMA wins (measured at B=16: block 2, K 192..720: 2.62 -> 2.33 ms with 64 rows;
                 // block 3, K 384..2064: 4.86 ms with 128 rows, 5.06 with 64)
                 const int rows = knobs().k1x1_rows ? knobs().k1x1_rows : (a.c_in_ld <= 768 ? 64 : 128);
-                return rows == 64 ? launch_conv1x1<192, 2>(a, s) : launch_conv1x1<192>(a, s);
+                if (rows == 64) return knobs().k1x1_sb ? launch_conv1x1<192, 2, true>(a, s) : launch_conv1x1<192, 2>(a, s);
+                return launch_conv1x1<192>(a, s);
             }
             if (wide == 256) return launch_conv1x1<256>(a, s);
             return launch_conv1x1<128>(a, s);
