@@ -109,8 +109,8 @@ def trace_to_rocprof_name(kernel):
     m = re.match(r"conv_halo_kernel<(\d+),k(\d),(nhwc|nchw)(,tail)?(,w8)?>", kernel)
     if m:
         wm = "8" if m.group(5) else (r"\d+" if m.group(1) != "48" else "4")      # the 48-wide tile has a 4- and an 8-wave variant
-        return r"conv_halo_kernel<%s,%s,\d+,\d+,%s,%s,%s>" % (m.group(1), wm, m.group(2), "true" if m.group(3) == "nchw" else "false",
-                                                            "true" if m.group(4) else "false")
+        return r"conv_halo_kernel<%s,%s,\d+,\d+,%s,%s,%s(,true|,false)?>" % (m.group(1), wm, m.group(2), "true" if m.group(3) == "nchw" else "false",
+                                                                            "true" if m.group(4) else "false")      # 8th: single weight buffer
     return None
 
 

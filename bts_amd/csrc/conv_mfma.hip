@@ -44,6 +44,7 @@ struct ConvKnobs {
     int k1x1_rows;                                         // BTS_CONV_1X1_ROWS: 0 = by K (default), 64 / 128 force the wide kernel's row tile
     int stem;                                              // BTS_CONV_STEM: 0 = the stem on the generic row-tiled kernel (A/B), default 1
     int tapskip;                                           // BTS_CONV_TAPSKIP: 0 = run every tap of every tile (A/B), default 1
+    int halo_sb;                                           // BTS_CONV_HALO_SB: 1 (default) = the 128-wide halo tile (no planar tail) keeps one weight buffer: two workgroups per CU
     int halo48_w8; long halo48_w8_below;                   // BTS_CONV_HALO48_W8 (0 = never) / _BELOW: 8-wave 48-wide halo tile for declared launches below this many workgroups (512)
     long halo_fill;                                        // BTS_CONV_HALO_FILL: declared-launch workgroups from which the halo kernel replaces split-K (200)
     int fill_frames;                                       // BTS_CONV_FILL_FRAMES: default of bts_conv_desc.fill_frames (8)
@@ -57,7 +58,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
                                 (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1),
                                 (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 150),
-                                (int)env_long("BTS_CONV_1X1_SB", 1), (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), (int)env_long("BTS_CONV_HALO48_W8", 1), env_long("BTS_CONV_HALO48_W8_BELOW", 512), env_long("BTS_CONV_HALO_FILL", 200),
+                                (int)env_long("BTS_CONV_1X1_SB", 1), (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), (int)env_long("BTS_CONV_HALO_SB", 1), (int)env_long("BTS_CONV_HALO48_W8", 1), env_long("BTS_CONV_HALO48_W8_BELOW", 512), env_long("BTS_CONV_HALO_FILL", 200),
                                 (int)(env_long("BTS_CONV_FILL_FRAMES", 8) > 0 ? env_long("BTS_CONV_FILL_FRAMES", 8) : 8),
                                 (int)env_long("BTS_CONV_HALO", 1)};
     return k;
@@ -1036,11 +1037,11 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
         const long halo_wgs = (long)a.fill_frames * ((a.H + 128 / mf - 1) / (128 / mf)) * ((a.W + mf - 1) / mf) * probe.n_ntiles * a.n_classes;
         if ((knobs().halo >= 2 || split_factor(probe, wsf) <= 1 || halo_wgs >= knobs().halo_fill) && halo_eligible(a, true, mf, nullptr)) {
             if (a.subpix) {
-                if (bn == 128) return launch_halo<128, 4, 2, 32, 2>(a, nchw, s);
+                if (bn == 128) return knobs().halo_sb ? launch_halo<128, 4, 2, 32, 2, false, true>(a, nchw, s) : launch_halo<128, 4, 2, 32, 2>(a, nchw, s);
                 if (bn == 64) return launch_halo<64, 4, 2, 32, 2>(a, nchw, s);
                 if (bn == 32) return launch_halo<32, 4, 1, 32, 2>(a, nchw, s);
             } else {
-                if (bn == 128) return launch_halo<128, 4, 2, 32, 3>(a, nchw, s);
+                if (bn == 128) return knobs().halo_sb ? launch_halo<128, 4, 2, 32, 3, false, true>(a, nchw, s) : launch_halo<128, 4, 2, 32, 3>(a, nchw, s);
                 if (bn == 64) return launch_halo<64, 4, 2, 32, 3>(a, nchw, s);
                 if (bn == 32) return launch_halo<32, 4, 1, 32, 3>(a, nchw, s);
                 if (bn == 48) {

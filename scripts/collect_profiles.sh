@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's measurement set on a 1-GPU box into gpurun_out/$1 (copy what should be judged into profiles/).
-#   bash scripts/collect_profiles.sh r02
+#   bash scripts/collect_profiles.sh r02g [r02]      (scratch tag, round prefix of the files under profiles/)
 # Separate rocprofv3 passes as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE cannot share a pass; no
 # --pmc together with system traces).  The program after `--` is python3 itself (no env / bash -c hops).
 set -o pipefail
@@ -10,9 +10,6 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py"
-echo "== bench (full line: cpu baseline, parity gate, emulated leg)"; 
-timeout -k 10 400 python3 "$B" --steps 20 --warmup 5 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err" || echo "bench failed rc=$?"
-tail -1 "$OUT/bench_n1.err"
 echo "== rocprofv3 kernel stats, default command"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$B" --no-cpu-baseline --no-emulated-leg > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err" || echo "stats failed"
 echo "== rocprofv3 kernel stats, --streams 1"
@@ -22,6 +19,13 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 echo "== PMC WRITE_SIZE"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$B" --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-emulated-leg --streams 1 > /dev/null 2> "$OUT/pmc_write.err" || echo "write failed"
 python3 "$ROOT/scripts/pmc_traffic.py" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt" 2>&1 || echo "pmc_traffic.py failed"
+# the full bench line comes AFTER the counter passes: bench.py quotes roofline.traffic from profiles/<round>_pmc_traffic.json,
+# and only while that file carries the hash of the kernel sources in the tree -- i.e. this pass's own measurement
+ROUND=${2:-r02}
+[ -s "$OUT/pmc_traffic.json" ] && cp "$OUT/pmc_traffic.json" "$ROOT/profiles/${ROUND}_pmc_traffic.json"
+echo "== bench (full line: cpu baseline, parity gate, emulated leg, PMC traffic of this pass)"
+timeout -k 10 400 python3 "$B" --steps 20 --warmup 5 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err" || echo "bench failed rc=$?"
+tail -1 "$OUT/bench_n1.err"
 echo "== PMC MFMA / waits"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- python3 "$B" --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-emulated-leg > /dev/null 2> "$OUT/pmc_mfma.err" || echo "mfma failed"
 python3 "$ROOT/scripts/pmc_summarize.py" "$OUT/pmc_mfma" "$OUT/pmc_mfma.json" > /dev/null 2>&1 || echo "pmc_summarize failed"
