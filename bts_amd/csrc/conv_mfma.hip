@@ -44,8 +44,8 @@ struct ConvKnobs {
     int k1x1_rows;                                         // BTS_CONV_1X1_ROWS: 0 = by K (default), 64 / 128 force the wide kernel's row tile
     int stem;                                              // BTS_CONV_STEM: 0 = the stem on the generic row-tiled kernel (A/B), default 1
     int tapskip;                                           // BTS_CONV_TAPSKIP: 0 = run every tap of every tile (A/B), default 1
-    int halo_sb;                                           // BTS_CONV_HALO_SB: 1 (default) = the 128-wide halo tile (no planar tail) keeps one weight buffer: two workgroups per CU
-    int halo48_w8; long halo48_w8_below;                   // BTS_CONV_HALO48_W8 (0 = never) / _BELOW: 8-wave 48-wide halo tile for declared launches below this many workgroups (512)
+    int halo_sb;                                           // BTS_CONV_HALO_SB: 1 (default) = the 128- and 32-wide halo tiles (no planar tail) keep one weight buffer: two / three workgroups per CU instead of one / two
+    int halo48_w8; long halo48_w8_below;                   // BTS_CONV_HALO48_W8 (0 = never) / _BELOW: 8-wave 48-wide halo tile for declared launches below this many workgroups (default: all)
     long halo_fill;                                        // BTS_CONV_HALO_FILL: declared-launch workgroups from which the halo kernel replaces split-K (200)
     int fill_frames;                                       // BTS_CONV_FILL_FRAMES: default of bts_conv_desc.fill_frames (8)
     int halo;                                              // BTS_CONV_HALO: 0 off, 1 = halo-tile kernel where eligible unless split-K applies, 2 = also instead of split-K.  Default 1: on the deep 22x76 maps a frame has only 15 spatial tiles, so at batch 1 split-K fills the chip 7x better (53 vs 16 us per layer), and the choice may not depend on the batch (a frame's bits must not)
@@ -58,7 +58,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_PRECISION", -1), (int)env_long("BTS_CONV_EMU_SB", -1),
                                 (int)env_long("BTS_CONV_W8", 1), (int)env_long("BTS_CONV_W8S", 1),
                                 (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 150),
-                                (int)env_long("BTS_CONV_1X1_SB", 1), (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), (int)env_long("BTS_CONV_HALO_SB", 1), (int)env_long("BTS_CONV_HALO48_W8", 1), env_long("BTS_CONV_HALO48_W8_BELOW", 512), env_long("BTS_CONV_HALO_FILL", 200),
+                                (int)env_long("BTS_CONV_1X1_SB", 1), (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), (int)env_long("BTS_CONV_HALO_SB", 1), (int)env_long("BTS_CONV_HALO48_W8", 1), env_long("BTS_CONV_HALO48_W8_BELOW", 1L << 40), env_long("BTS_CONV_HALO_FILL", 200),
                                 (int)(env_long("BTS_CONV_FILL_FRAMES", 8) > 0 ? env_long("BTS_CONV_FILL_FRAMES", 8) : 8),
                                 (int)env_long("BTS_CONV_HALO", 1)};
     return k;
@@ -1039,14 +1039,16 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
             if (a.subpix) {
                 if (bn == 128) return knobs().halo_sb ? launch_halo<128, 4, 2, 32, 2, false, true>(a, nchw, s) : launch_halo<128, 4, 2, 32, 2>(a, nchw, s);
                 if (bn == 64) return launch_halo<64, 4, 2, 32, 2>(a, nchw, s);
-                if (bn == 32) return launch_halo<32, 4, 1, 32, 2>(a, nchw, s);
+                if (bn == 32) return knobs().halo_sb ? launch_halo<32, 4, 1, 32, 2, false, true>(a, nchw, s) : launch_halo<32, 4, 1, 32, 2>(a, nchw, s);
             } else {
                 if (bn == 128) return knobs().halo_sb ? launch_halo<128, 4, 2, 32, 3, false, true>(a, nchw, s) : launch_halo<128, 4, 2, 32, 3>(a, nchw, s);
                 if (bn == 64) return launch_halo<64, 4, 2, 32, 3>(a, nchw, s);
-                if (bn == 32) return launch_halo<32, 4, 1, 32, 3>(a, nchw, s);
+                if (bn == 32) return knobs().halo_sb ? launch_halo<32, 4, 1, 32, 3, false, true>(a, nchw, s) : launch_halo<32, 4, 1, 32, 3>(a, nchw, s);
                 if (bn == 48) {
-                    // fewer declared workgroups than 2 per CU (DenseNet block 3: 240 at fill_frames 16): eight waves per
-                    // workgroup (one 16-pixel row each) instead of four, so the CUs that do get a tile run it with twice the waves
+                    // eight waves per workgroup (one 16-pixel row each) instead of four: 16 instead of 8 waves per CU at two
+                    // workgroups per CU.  Worth -10 % where the launch is under-filled (DenseNet block 3: 240 workgroups at
+                    // fill_frames 16) and -2 % on the chip-filling block 1 / 2 launches; BTS_CONV_HALO48_W8_BELOW restricts it
+                    // to declared launches below that many workgroups (A/B)
                     if (knobs().halo48_w8 && halo_wgs < knobs().halo48_w8_below) return launch_halo<48, 8, 1, 16, 3>(a, nchw, s);
                     return launch_halo<48, 4, 1, 16, 3>(a, nchw, s);
                 }
