@@ -260,3 +260,47 @@ def test_tap_skipping_off_where_it_cannot_apply():
     """1x1 convolutions and split-K launches report no skipping (issued == dense or both 0)."""
     issued, dense, _, kind = _ksteps(2, 44, 152, 256, 256, 1, 1, 0)
     assert issued == dense
+
+
+# ------------------------------------------------------------------------------------------ dispatch vs declared fill (host side)
+def _plan(B, h, w, cin, cout, k, fill, ws_floats=1 << 28):
+    """(kernel kind, bm, bn) bts_conv_fwd_f32 would pick -- host-side query, pointers never dereferenced."""
+    import ctypes as C
+    from bts_amd import _lib
+    d = _lib.ConvDesc()
+    d.x = d.w = d.y = 0x1000
+    d.splitk_ws, d.splitk_ws_floats = 0x2000, ws_floats
+    d.x_pix_stride = cin
+    d.c_in_ld = cin
+    d.k_pad = (k * k * cin + 31) // 32 * 32
+    d.B, d.h_in, d.w_in, d.up = B, h, w, 1
+    d.ksize, d.dil, d.stride, d.pad = k, 1, 1, k // 2
+    d.c_out, d.c_out_pad = cout, (cout + 31) // 32 * 32
+    d.y_pix_stride = cout
+    d.fill_frames = fill
+    bm, bn, kind = C.c_int(0), C.c_int(0), C.c_int(0)
+    assert _lib.load_real().bts_conv_plan_f32(C.byref(d), C.byref(bm), C.byref(bn), C.byref(kind)) == 0
+    return kind.value, bm.value, bn.value
+
+
+def test_block3_kernel_choices_need_a_declaration_above_the_default():
+    """DenseNet block 3 (22x76 maps): the wide 1x1 tile and the halo kernel instead of split-K are only worth it when
+    enough frames share the launch.  The library default (fill_frames 0 -> 8) and a single-frame caller must stay on
+    the split-K / row-tiled kernels -- with the block-3 choices at the default, batch 1 cost 12.0 instead of 8.3 ms per
+    frame -- while a caller that declares 16 frames (bench.py at B=16) gets them.  Never a function of B."""
+    for B in (1, 16):
+        for fill in (0, 1, 2, 8):
+            kind, bm, bn = _plan(B, 22, 76, 1248, 192, 1, fill)
+            assert kind & 15 == 0, (B, fill, kind)                 # row-tiled kernel
+            kind, _, bn = _plan(B, 22, 76, 192, 48, 3, fill)
+            assert kind & 15 == 0 and kind & 16 and bn == 48, (B, fill, kind)      # row-tiled + split-K
+        kind, bm, bn = _plan(B, 22, 76, 1248, 192, 1, 16)
+        assert kind & 15 == 3 and (bm, bn) == (128, 192), (B, kind, bm, bn)       # wide 1x1, 128-row tile (K > 768)
+        kind, bm, bn = _plan(B, 22, 76, 432, 192, 1, 16)
+        assert kind & 15 == 3 and (bm, bn) == (64, 192)                             # K <= 768: 64-row tile
+        kind, _, bn = _plan(B, 22, 76, 192, 48, 3, 16)
+        assert kind & 15 == 1 and kind & 32 and not kind & 16 and bn == 48         # halo kernel, eight-wave 48-wide tile
+    # blocks 1-2 fill the chip at any declaration: wide 1x1 / halo kernels whatever the fill
+    for fill in (0, 1, 16):
+        assert _plan(1, 88, 304, 240, 192, 1, fill)[0] & 15 == 3
+        assert _plan(1, 88, 304, 192, 48, 3, fill)[0] & 15 == 1
