@@ -186,8 +186,12 @@ typedef struct bts_conv_desc {
                                 whether the wide 1x1 tile has enough pixel tiles) are sized for fill_frames x H x W pixels.
                                 They are NEVER derived from B itself -- a frame's bits must not depend on its batch -- so a
                                 caller that runs single frames (the reference's test loop, pytorch/bts_test.py:127-147) says
-                                so here: fill_frames = 1 splits K on many more layers (352x1216, batch 1: 8.8 -> 6.4 ms of GPU
-                                time per frame).  Results of different fill_frames differ in summation order (fp32 rounding) */
+                                so here: fill_frames = 1 or 2 splits K on many more layers (352x1216, batch 1: 8.2 -> 5.7 ms of
+                                GPU time per frame).  A batched caller declares the frames that share the chip (bench.py: its
+                                per-GPU batch, at most 16): from 12-14 frames on, the DenseNet block-3 layers (22x76 maps) move
+                                from the split-K kernels to the wide 1x1 tile and the halo kernel -- choices that would cost a
+                                single-frame caller 45 % if they were tied to the default.  Results of different fill_frames
+                                differ in summation order (fp32 rounding)                                                  */
 } bts_conv_desc;
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);
