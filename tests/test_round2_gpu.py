@@ -783,3 +783,48 @@ def test_tap_skipping_leaves_every_bit_unchanged(dil, shape):
     ref = torch.nn.functional.conv2d(xin, wt.double(), dilation=dil, padding=dil)
     got = y.double().reshape(B, h, w, 128).permute(0, 3, 1, 2)
     assert (got - ref).abs().max().item() / ref.abs().max().item() <= 3e-6
+
+
+# ------------------------------------------------------------------------------ the declaration bench.py runs with
+def test_fill_frames_16_block3_on_wide_and_halo_kernels_frame_independent_cpu_parity():
+    """bench.py declares fill_frames 16 at B=16: DenseNet block 3 then runs on the wide 1x1 tile and the eight-wave 48-wide
+    halo tile instead of the row-tiled / split-K kernels (checked through the launch trace).  At full size (B=16,
+    352x1216, four sub-batch streams): frames 0 and 15 of the batch bit-equal to the same frames run alone under the same
+    declaration, the result within fp32 summation noise of the default declaration, and frame 0 vs the torch-CPU encoder
+    + CPU oracle decoder."""
+    from bts_amd import ops
+    enc, dataset, B, H, W = "densenet161_bts", "kitti", 16, 352, 1216
+    m = _model(enc, dataset).cuda()
+    m.sub_batches = 4
+    img = t(synth.image_batch(B, H, W, 4321))
+    foc = t(synth.focal_values(B, dataset, 4321))
+    try:
+        with torch.no_grad():
+            dflt = [o.clone() for o in m(img.cuda(), foc.cuda())]
+            assert ops.set_fill_frames(16) == 0
+            full = [o.clone() for o in m(img.cuda(), foc.cuda())]
+            tr = ops.KernelTrace()
+            ops.set_trace(tr)
+            try:
+                one0 = [o.clone() for o in m(img[0:1].cuda(), foc[0:1].cuda())]
+            finally:
+                ops.set_trace(None)
+            b3 = {r[1]: set() for r in tr.records if r[1].startswith("enc_b3")}
+            for r in tr.records:
+                if r[1] in b3:
+                    b3[r[1]].add(r[0])
+            assert b3["enc_b3_1x1"] == {"conv1x1_kernel<192,2>", "conv1x1_kernel<192,4>"}, b3
+            assert b3["enc_b3_3x3"] == {"conv_halo_kernel<48,k3,nhwc,w8>"}, b3
+            one15 = m(img[15:16].cuda(), foc[15:16].cuda())
+            for a, b, c in zip(one0, one15, full):
+                assert torch.equal(a[0], c[0]) and torch.equal(b[0], c[15]), "a frame depends on its batch under fill_frames=16"
+            for a, b in zip(full, dflt):
+                assert (a - b).abs().max().item() / b.abs().max().item() < 2e-5
+            assert not all(torch.equal(a, b) for a, b in zip(full, dflt)), "the declaration changed nothing"
+            cpu = copy.deepcopy(m).cpu()
+            feats = cpu.encoder(img[0:1])
+            state = {k: v for k, v in cpu.decoder.state_dict().items()}
+            ref_outs, inter = O.decoder_forward(state, feats, foc[0:1], 80.0, dataset, want_intermediates=True)
+    finally:
+        ops.set_fill_frames(0)
+    check_outputs([o[0:1] for o in full], ref_outs, inter, rel_tol=1e-4, what="fill_frames 16, frame 0")
