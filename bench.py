@@ -557,6 +557,23 @@ def main():
                         e.update(achieved_tflops=round(tf, 2), frac_mfma=round(tf / PEAK_MFMA_F32_TFLOPS, 4))
                 groups[t] = e
             roof["groups"] = groups
+            # SURVEY.md section 8(d)'s own roofline definitions for the hot path proper: ASPP = algorithmic FLOP of the five
+            # branches / their time against the fp32-MFMA peak; reductions + LPG (fused: one launch per scale + reduc1x1) =
+            # algorithmic bytes / their time against 8 TB/s
+            def _t(name, key):
+                return tags.get(name, {}).get(key, 0.0)
+            if _t("aspp", "ms") > 0:
+                tf = _t("aspp", "flops") / (_t("aspp", "ms") * 1e-3) / 1e12
+                hp = {"aspp": {"gflop_per_step": round(_t("aspp", "flops") / nrep / 1e9, 2), "ms_per_step": round(_t("aspp", "ms") / nrep, 3),
+                               "achieved_tflops": round(tf, 2), "frac_mfma": round(tf / PEAK_MFMA_F32_TFLOPS, 4),
+                               "executed_tflops": round(_t("aspp", "xflops") / (_t("aspp", "ms") * 1e-3) / 1e12, 2)}}
+                rms = _t("reduc", "ms") + _t("reduc_lpg", "ms")
+                if rms > 0:
+                    rb = _t("reduc", "bytes") + _t("reduc_lpg", "bytes")
+                    gbs = rb / (rms * 1e-3) / 1e9
+                    hp["reduction_lpg"] = {"mb_per_step": round(rb / nrep / 1e6, 1), "ms_per_step": round(rms / nrep, 3), "gbs": round(gbs, 1),
+                                           "frac_hbm": round(gbs / PEAK_HBM_GBS, 4)}
+                roof["survey_8d"] = hp
             kern = {}
             for k, v in summ.items():
                 e = {"ms_per_step": round(v["ms"] / nrep, 4), "launches_per_step": v["launches"] // nrep}
