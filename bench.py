@@ -12,7 +12,10 @@ the hand-written HIP kernels of libbts_hip.so -- at B=16 per GPU, 3x352x1216 fp3
 Weak scaling by default (--batch frames per GPU); --global-batch G fixes the total and shards it.  `n_gpus` in the
 JSON line is the number of ranks RCCL actually formed; a mismatch with --gpus is an error, never a silent 1-GPU run.
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant hand-written
-kernel, HIP-event timed on its launch stream) and `cpu_baseline` (the CPU oracle on the host cores).
+kernel, HIP-event timed on its launch stream; `roofline.survey_8d` = SURVEY.md section 8(d)'s own definitions for the
+ASPP branches and the fused reduction + LPG launches; `roofline.groups` / `.kernels` = every call site / kernel family)
+and `cpu_baseline` (the CPU oracle on the host cores).  `config.fill_frames` is the frames-per-launch declaration the
+library's tile / split-K choices were sized for (the per-GPU batch, at most 16).
 """
 import argparse
 import json
