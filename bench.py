@@ -269,16 +269,20 @@ def launch_ranks(args, argv):
             return 2
     port = args.master_port or _free_port()
     procs = []
+    # rank 0's stdout (the one JSON line) goes to a temporary file, read after the ranks have exited: the parent never
+    # blocks on a pipe, so the 50 ms poll below is what notices a dying rank -- whichever rank it is -- and stops the
+    # others (a rank > 0 that dies would otherwise leave rank 0 inside a collective until the RCCL timeout)
+    import tempfile
+    out0_file = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+                                      stdout=out0_file if r == 0 else sys.stderr))
     rc = 0
-    out0 = b""
     try:
-        # rank 0's stdout is one JSON line: read it to EOF, then reap everyone; a rank that dies takes the others with it
         pending = set(range(n))
+        deadline = None                                    # set once a rank has failed: survivors get 10 s to obey SIGTERM
         while pending:
             for r in sorted(pending):
                 code = procs[r].poll()
@@ -289,20 +293,22 @@ def launch_ranks(args, argv):
                         print("bench.py: rank %d exited with code %d; stopping the other ranks" % (r, code), file=sys.stderr)
                         for q in pending:
                             procs[q].terminate()
-            if 0 in pending:
-                try:
-                    out0 += procs[0].stdout.read1(65536) if hasattr(procs[0].stdout, "read1") else b""
-                except Exception:
-                    pass
-            time.sleep(0.05)
-        out0 += procs[0].stdout.read() or b""
+                        deadline = time.monotonic() + 10.0
+            if deadline is not None and pending and time.monotonic() > deadline:
+                for q in pending:
+                    procs[q].kill()
+                deadline = time.monotonic() + 3600.0
+            if pending:
+                time.sleep(0.05)
     finally:
         for q in procs:
             if q.poll() is None:
                 q.kill()
     if rc == 0:
-        sys.stdout.write(out0.decode())
+        out0_file.seek(0)
+        sys.stdout.write(out0_file.read().decode())
         sys.stdout.flush()
+    out0_file.close()
     return rc
 
 
@@ -321,6 +327,10 @@ def launcher_selftest(args, world, rank):
     from bts_amd import dist as bdist
     dist.init_process_group(backend="gloo")
     formed = dist.get_world_size()
+    if os.environ.get("BTS_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+        # failure injection (tests/test_bench_launcher.py): this rank dies after the rendezvous while the others go on
+        # into a collective they can never finish -- the launcher must notice and stop them
+        os._exit(7)
     b, G, scaling = shard_plan(args, formed)
     lo, hi = bdist.shard_range(G, rank, formed)
     assert hi - lo == b, "equal contiguous shards"

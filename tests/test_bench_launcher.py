@@ -67,6 +67,21 @@ def test_under_torchrun_world_size_must_match_gpus():
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
 
 
+@pytest.mark.parametrize("victim", [1, 0])
+def test_one_dying_rank_stops_the_others_promptly(victim):
+    """Only ONE rank fails (after the rendezvous, while the other is inside a collective): the parent must notice through
+    its poll loop, terminate the survivor and return that rank's code -- not sit on rank 0's stdout until a collective
+    times out (gloo's default: 30 minutes)."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-selftest"],
+                       env=dict(_env(), BTS_BENCH_SELFTEST_FAIL_RANK=str(victim)), capture_output=True, text=True, timeout=240)
+    assert r.returncode == 7, (r.returncode, r.stderr[-1500:])
+    assert "rank %d exited with code 7" % victim in r.stderr
+    assert r.stdout.strip() == ""                       # no JSON line from a run that lost a rank
+    assert time.time() - t0 < 120
+
+
 def test_uneven_global_batch_is_rejected():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-selftest", "--global-batch", "7"], env=_env(),
                        capture_output=True, text=True, timeout=300)
