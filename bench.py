@@ -239,9 +239,9 @@ def build_parser():
                     help="run the per-GPU batch as this many concurrent sub-batches on separate HIP streams (one graph): "
                          "frames are independent, so under-filled launches of one sub-batch overlap the other's")
     ap.add_argument("--fill-frames", type=int, default=0,
-                    help="frames per launch the library's split-K / tile choices are sized for (bts_conv_desc.fill_frames). "
-                         "0 = the per-GPU batch, at most 16: the frames that really share the chip (4 sub-batch streams "
-                         "in flight).  The library default (8) is sized for callers that declare nothing")
+                    help="pin BtsModel.fill_frames (frames per launch the library's split-K / tile choices are sized for, "
+                         "bts_conv_desc.fill_frames).  0 = leave the model's default: by the batch of the call "
+                         "(B <= 2 -> 2, B <= 11 -> 8, else 16)")
     ap.add_argument("--decoder-only", action="store_true", help="time only the decoder hot path on encoder-shaped features")
     ap.add_argument("--encoder-backend", choices=["hip", "aten", "miopen"], default="hip",
                     help="hip: DenseNet encoder on the HIP conv kernel (default); aten: torch encoder on ATen's native "
@@ -312,14 +312,18 @@ def launch_ranks(args, argv):
     return rc
 
 
-def shard_plan(args, world):
-    """(frames per rank, global batch, scaling label).  Weak: --batch per GPU.  Strong: --global-batch split into equal
-    contiguous blocks (DataParallel.scatter order, bts_test.py:91)."""
+def shard_plan(args, world, rank=0):
+    """(frames of THIS rank, frames of the largest rank, global batch, scaling label).  Weak: --batch per GPU.  Strong:
+    --global-batch split into contiguous blocks, the first G % world ranks one frame longer (DataParallel.scatter
+    order, bts_test.py:91; bts_amd.dist.shard_range) -- a batch the ranks do not divide is sharded unevenly, the gather
+    pads and trims it (dist.DepthGather)."""
     if args.global_batch > 0:
-        if args.global_batch % world:
-            raise SystemExit("bench.py: --global-batch %d is not a multiple of %d ranks" % (args.global_batch, world))
-        return args.global_batch // world, args.global_batch, "strong"
-    return args.batch, args.batch * world, "weak"
+        from bts_amd import dist as bdist
+        if args.global_batch < world:
+            raise SystemExit("bench.py: --global-batch %d is smaller than the %d ranks" % (args.global_batch, world))
+        lo, hi = bdist.shard_range(args.global_batch, rank, world)
+        return hi - lo, -(-args.global_batch // world), args.global_batch, "strong"
+    return args.batch, args.batch, args.batch * world, "weak"
 
 
 def launcher_selftest(args, world, rank):
@@ -331,9 +335,9 @@ def launcher_selftest(args, world, rank):
         # failure injection (tests/test_bench_launcher.py): this rank dies after the rendezvous while the others go on
         # into a collective they can never finish -- the launcher must notice and stop them
         os._exit(7)
-    b, G, scaling = shard_plan(args, formed)
+    b, b_max, G, scaling = shard_plan(args, formed, rank)
     lo, hi = bdist.shard_range(G, rank, formed)
-    assert hi - lo == b, "equal contiguous shards"
+    assert hi - lo == b <= b_max, "contiguous shards, at most one frame apart"
     m = torch.nn.Linear(4, 3)
     with torch.no_grad():
         m.weight.fill_(float(rank + 1))
@@ -342,14 +346,16 @@ def launcher_selftest(args, world, rank):
     outs = [torch.full((b, 1, 2, 3), float(10 * rank + i)) for i in range(6)]
     dist.barrier()
     t0 = time.perf_counter()
-    gathered, work = bdist.all_gather_depths(outs, 5, async_op=True)
+    gathered, work = bdist.all_gather_depths(outs, 5, async_op=True, global_batch=G)
     work.wait()
     dist.barrier()
     tt = torch.tensor([time.perf_counter() - t0 + 0.001 * rank], dtype=torch.float64)
     mine = float(tt.item())
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    maps = bdist.unshard_depths(gathered)
-    ok = all(float(maps[i][r * b, 0, 0, 0]) == 10 * r + i for i in range(5) for r in range(formed))
+    maps = bdist.unshard_depths(gathered, G)
+    starts = [bdist.shard_range(G, r, formed) for r in range(formed)]
+    ok = all(tuple(maps[i].shape) == (G, 1, 2, 3) for i in range(5)) and \
+        all(float(maps[i][f, 0, 0, 0]) == 10 * r + i for i in range(5) for r, (a, e) in enumerate(starts) for f in range(a, e))
     line = {"selftest": "launcher", "n_gpus": formed, "requested_gpus": args.gpus, "scaling": scaling,
             "global_batch": G, "batch_per_gpu": b, "shard": [lo, hi], "gather_ok": bool(ok),
             "elapsed_is_max_over_ranks": bool(float(tt.item()) >= mine), "value": None, "backend": "gloo"}
@@ -408,23 +414,21 @@ def main():
     from bts_amd import dist as bdist, ops, synth
     is_kitti = args.dataset == "kitti"
     params = Params(args.encoder, 512, 80.0 if is_kitti else 10.0, "kitti" if is_kitti else "nyu")
-    B, G, scaling = shard_plan(args, world)
+    B, B_max, G, scaling = shard_plan(args, world, rank)
     H, W = args.height, args.width
     log("building model %s" % args.encoder)
     S = max(1, args.streams)
     while S > 1 and B % S:
         S -= 1
-    # The caller declares how many frames share the chip: the library never derives it from the batch (a frame's bits
-    # must not depend on its neighbours).  bench.py runs its B frames as S concurrent sub-batches, so B frames are in
-    # flight: it declares B (at most 16).  $BTS_CONV_FILL_FRAMES (A/B runs) wins when set.
-    fill_frames = args.fill_frames if args.fill_frames > 0 else max(1, min(16, B))
-    if "BTS_CONV_FILL_FRAMES" not in os.environ:
-        ops.set_fill_frames(fill_frames)
-    else:
-        fill_frames = int(os.environ["BTS_CONV_FILL_FRAMES"])
+    # The model declares how many frames share the chip (BtsModel.fill_frames -> bts_conv_desc.fill_frames).  Left at
+    # None it follows the batch of the call in three classes (ops.auto_fill_frames: B >= 12 -> 16, the B frames that
+    # bench.py keeps in flight as S concurrent sub-batches); --fill-frames / $BTS_CONV_FILL_FRAMES (A/B runs) pin it.
+    pinned_fill = int(os.environ["BTS_CONV_FILL_FRAMES"]) if "BTS_CONV_FILL_FRAMES" in os.environ else (args.fill_frames or None)
+    fill_frames = pinned_fill if pinned_fill else ops.auto_fill_frames(B)
     model = build_model(params, device, seed=0)
     model.native_encoder = args.encoder_backend == "hip"
     model.sub_batches = S
+    model.fill_frames = model.decoder.fill_frames = pinned_fill
     bdist.broadcast_module(model, src=0)            # RCCL broadcast of ~188 MB, once
     log("model on %s (%d concurrent sub-batch%s)" % (device, S, "es" if S > 1 else ""))
 
@@ -435,64 +439,83 @@ def main():
         fe = synth.encoder_features(synth.ENCODER_CHANNELS[args.encoder], B, H, W, 1234 + rank)
         feats_static = [None] + [torch.from_numpy(f).to(device) for f in fe[1:]]
 
-    def forward():
+    # N > 1: the five depth maps of every step are all-gathered (one collective).  The model writes them straight into
+    # the persistent send buffer (BtsModel.output_buffers = views of dist.DepthGather's packed buffer: no pack copy, no
+    # per-step allocation); two slots -- two captured graphs -- alternate, so step i+1 computes into the other slot
+    # while the collective of step i is still reading its own.
+    gather = use_dist and not args.no_gather and not args.decoder_only
+    dg = bdist.DepthGather(5, B_max, H, W, device, slots=2) if gather else None
+    n_slots = 2 if gather else 1
+
+    def forward(slot=0):
         if feats_static is not None:
             return model.decoder(feats_static, focal)
+        model.output_buffers = dg.outputs(slot, B) if dg is not None else None
         return model(image, focal)
 
     use_graph = not args.no_graph
     graph, outs = None, None
+    graphs, outs_slot = [None] * n_slots, [None] * n_slots
     with torch.no_grad():
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for i in range(2):                     # eager passes: MIOpen kernel selection, weight packing, workspaces
-                outs = forward()
+                outs = forward(i % n_slots)
                 torch.cuda.synchronize()
                 log("eager pass %d done" % i)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if use_graph:
             try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    outs = forward()
-                graph.replay()
-                torch.cuda.synchronize()
+                for sl in range(n_slots):
+                    graphs[sl] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graphs[sl]):
+                        outs_slot[sl] = forward(sl)
+                    graphs[sl].replay()
+                    torch.cuda.synchronize()
+                graph, outs = graphs[0], outs_slot[0]
             except Exception as e:                 # report, never hide: the JSON says graph=false
                 if rank == 0:
                     print("[bench] hipGraph capture failed, running eager: %r" % (e,), file=sys.stderr)
                 graph = None
                 torch.cuda.synchronize()
 
-        gather = use_dist and not args.no_gather
-        pending = [None]
+        pending = [None] * n_slots
+        step_no = [0]
 
         def step():
             nonlocal outs
+            sl = step_no[0] % n_slots
+            step_no[0] += 1
+            if pending[sl] is not None:            # the collective that last read this slot's send buffer
+                pending[sl].wait()
+                pending[sl] = None
             if graph is not None:
-                graph.replay()
+                graphs[sl].replay()
+                outs = outs_slot[sl]
             else:
-                outs = forward()
+                outs = forward(sl)
             if gather:
-                if pending[0] is not None:
-                    pending[0][1].wait()
-                pending[0] = bdist.all_gather_depths(outs, 5, async_op=True)
+                pending[sl] = dg.gather(sl, async_op=True)
+
+        def drain():
+            for sl in range(n_slots):
+                if pending[sl] is not None:
+                    pending[sl].wait()
+                    pending[sl] = None
 
         log("hipgraph=%s; warm-up" % (graph is not None))
         for _ in range(args.warmup):
             step()
-        if pending[0] is not None:
-            pending[0][1].wait()
-            pending[0] = None
+        drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        if pending[0] is not None:
-            pending[0][1].wait()
+        drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -605,7 +628,7 @@ def main():
             roof["hip_kernels_ms_per_step"] = round(sum(v["ms"] for v in summ.values()) / nrep, 3)
 
     if rank == 0:
-        fps = world * B * args.steps / elapsed
+        fps = G * args.steps / elapsed                       # whole-job frames (all ranks) over the slowest rank's time
         line = {
             "metric": "depth frames/sec at B=16, 352x1216 KITTI input",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -627,7 +650,7 @@ def main():
             # Secondary measurement, NOT the headline: the same forward with every convolution in the
             # "fp32 emulated on the bf16 matrix cores" mode (bts_conv_desc.precision = 1: three-way bf16 split of both
             # operands, six products, fp32 accumulation -- results at fp32 rounding level, see its own parity gate).
-            prev = ops.set_conv_precision("bf16x3")
+            model.conv_precision = model.decoder.conv_precision = "bf16x3"
             try:
                 with torch.no_grad():
                     forward()
@@ -665,7 +688,7 @@ def main():
                 print("[bench] emulated-fp32 leg failed and is omitted: %r" % (e,), file=sys.stderr)
                 torch.cuda.synchronize()
             finally:
-                ops.set_conv_precision(prev)
+                model.conv_precision = model.decoder.conv_precision = "fp32"
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")
             frame0 = timed_frame0             # outs[i][0:1] of the last timed step (graph replay or eager, as timed)

@@ -135,7 +135,7 @@ class atrous_conv(nn.Sequential):
 
     def run_nhwc(self, x2d, B, h, w, mid2d, y2d, splitk_ws=None):
         """Two launches: [BN]+ReLU -> 1x1 -> BN -> ReLU (mid), then dilated 3x3 into the y2d slice.  ``splitk_ws``:
-        scratch that lets the launches split K in single-frame mode (ops.set_fill_frames(1)); at the default setting
+        scratch that lets the launches split K in single-frame mode (fill_frames 1 / 2); at the default setting
         the H/8 maps fill the chip and never split."""
         p = self.packed()
         ops.conv_forward(x2d, B, h, w, p["w1"], p["c_mid"], 1, c_in_ld=p["c_in"], pre=p["pre"], pre_relu=True,
@@ -325,6 +325,8 @@ class bts(nn.Module):
         self.upconv4.tap_gemm = True
         self._packs = PackCache(self)
         self._bufs = WorkspaceCache(max_entries=8)      # per-shape NHWC workspaces; shared with replicas, graph-pinnable
+        self.fill_frames = None                         # launch declaration when the decoder is called on its own
+        self.conv_precision = "fp32"                    # (BtsModel.forward opens its own scope: see BtsModel.fill_frames)
 
     # ------------------------------------------------------------------ weight packing (lazy)
     _OWN = ("bn5", "conv5", "bn4", "conv4", "bn4_2", "daspp_conv", "bn3", "conv3", "bn2", "conv2", "conv1", "get_depth")
@@ -405,6 +407,12 @@ class bts(nn.Module):
 
     def forward(self, features, focal):
         """bts.forward(features, focal), bts.py:223-293: NCHW encoder taps in, the reference's 6-tuple out."""
+        if not ops.launch_config_active() and len(features) == 6 and isinstance(features[5], torch.Tensor):
+            with ops.model_launch_config(self, features[5].shape[0]):       # called on its own: the decoder's declaration
+                return self._forward(features, focal)
+        return self._forward(features, focal)
+
+    def _forward(self, features, focal):
         if len(features) != 6:
             raise BtsHipError("bts.forward: expected the encoder's 6-element tap list, got %d" % len(features))
         skip0, skip1, skip2, skip3, dense = features[1], features[2], features[3], features[4], features[5]
@@ -430,11 +438,12 @@ class bts(nn.Module):
             ops.nchw_to_nhwc(src, dst)
         return self.forward_nhwc(ws, B, H, W, focal, ws["f5"], None, False)
 
-    def forward_nhwc(self, ws, B, H, W, focal, dense2d, dense_pre, dense_relu, outs=None):
+    def forward_nhwc(self, ws, B, H, W, focal, dense2d, dense_pre, dense_relu, outs=None, abs_mins=None):
         """The decoder proper on NHWC buffers.  ``ws``: this module's workspace with the four skip slots
         already filled; ``dense2d``: the 1/32-resolution features [npix, C>=f[4]] and the prologue
         (affine, relu) still to be applied to them (norm5 + ReLU when the encoder is fused in).
-        ``outs``: optional 6 preallocated contiguous result tensors (e.g. batch slices of full-batch tensors)."""
+        ``outs``: optional 6 preallocated contiguous result tensors (e.g. batch slices of full-batch tensors).
+        ``abs_mins``: optional float32 [3] tensor that receives the three LPG ``abs_min`` scalars (8x8, 4x4, 2x2)."""
         if self.training:
             raise BtsHipError("bts.forward_nhwc is the fused inference path; train() mode goes through bts.forward "
                               "(bts_amd/train.py)")
@@ -473,8 +482,11 @@ class bts(nn.Module):
         self.daspp_24.run_nhwc(x8[:, :o_d + 4 * q], B, h8, w8, ws["mid"], x8[:, o_d + 4 * q:o_d + 5 * q], ws["splitk"])
         conv("daspp_conv", x8[:, o_d:], h8, w8, q, y2d=ws["daspp_feat"])
 
+        am_buf = abs_mins if abs_mins is not None else torch.empty(3, dtype=torch.float32, device=dev)
+        am_it = iter((am_buf[0], am_buf[1], am_buf[2]))
+
         def am():
-            return torch.empty((), dtype=torch.float32, device=dev)
+            return next(am_it)
 
         def out_tensor(i, c):
             if outs is not None:
@@ -574,6 +586,16 @@ class BtsModel(nn.Module):
         self.native_encoder = True          # set False to force the torch encoder (A/B, debugging)
         self.sub_batches = 4                # concurrent sub-batches (own HIP stream + workspace each); 1 = off
                                             # (MI355X, B=16: 1 -> 54.7, 2 -> 48.4, 4 -> 47.6, 8 -> 51.5 ms/step)
+        self.fill_frames = None             # frames per launch this model declares to the library (bts_conv_desc.fill_frames:
+                                            # sizes split-K and the tile family, so it changes fp32 summation order).
+                                            # None = by the batch of each call, in three classes (ops.auto_fill_frames:
+                                            # B <= 2 -> 2, the latency setting of bts_test.py's B=1 loop; B <= 11 -> 8;
+                                            # else 16); an int pins it, and a frame's bits then never depend on the batch
+        self.conv_precision = "fp32"        # "fp32": fp32-input MFMA; "bf16x3": fp32 emulated on the bf16 matrix cores
+        self.output_buffers = None          # optional: up to six preallocated contiguous result tensors ([B,1,H,W] x 5,
+                                            # [B,32,H,W]); entries given (not None) receive the results of the native eval
+                                            # forward IN PLACE instead of fresh tensors -- e.g. views of a persistent
+                                            # all-gather send buffer (dist.DepthGather.outputs): no pack copy per step
         self.use_plans = False              # True: record each (shape, slot) forward once, replay it with ONE library
                                             # call per forward afterwards (bts_amd/plan.py, bts_plan_run): the eager
                                             # B=1 loop of bts_test.py:127-147 without ~120 ctypes crossings per frame
@@ -585,12 +607,16 @@ class BtsModel(nn.Module):
         return (self.native_encoder and not self.training and isinstance(x, torch.Tensor) and x.is_cuda
                 and isinstance(self.encoder.base_model, (nn.Sequential, encoders.ResNet)))
 
-    def _forward_native(self, x, focal, slot, outs=None):
+    def _forward_native(self, x, focal, slot, outs=None, abs_mins=None):
         if self.use_plans and ops._trace is None and not _lib_mod.is_recording():
-            return self._plans.forward(self, x, focal, slot, outs)
-        return self._forward_native_eager(x, focal, slot, outs)
+            r = self._plans.forward(self, x, focal, slot, outs)
+            if abs_mins is not None:
+                dec = self.decoder
+                torch.stack([dec.lpg8x8.abs_min, dec.lpg4x4.abs_min, dec.lpg2x2.abs_min], out=abs_mins)
+            return r
+        return self._forward_native_eager(x, focal, slot, outs, abs_mins)
 
-    def _forward_native_eager(self, x, focal, slot, outs=None):
+    def _forward_native_eager(self, x, focal, slot, outs=None, abs_mins=None):
         from .encoder_hip import DenseNetHip, ResNetHip
         base = self.encoder.base_model
         src_base = self._origin[0].encoder.base_model      # a replica's packs are fingerprinted on the source model
@@ -607,7 +633,22 @@ class BtsModel(nn.Module):
         ws = dec._workspace(B, H, W, x.device, slot)
         r = plan.run(x.float(), dec.skip_slots(ws), slot=slot)
         # DenseNet: norm5 + ReLU become the prologue of the decoder's first conv; ResNet: layer4 is already ReLU'd
-        return dec.forward_nhwc(ws, B, H, W, focal, r["dense"], r["norm5"], r["norm5"] is not None, outs=outs)
+        return dec.forward_nhwc(ws, B, H, W, focal, r["dense"], r["norm5"], r["norm5"] is not None, outs=outs, abs_mins=abs_mins)
+
+    def _result_tensors(self, B, H, W, dev):
+        """The six result tensors of one native eval forward: ``output_buffers`` entries where given, fresh otherwise."""
+        nf16 = self.decoder.num_features // 16
+        given = list(self.output_buffers or [])
+        res = []
+        for i, c in enumerate((1, 1, 1, 1, 1, nf16)):
+            buf = given[i] if i < len(given) else None
+            if buf is None:
+                buf = torch.empty((B, c, H, W), dtype=torch.float32, device=dev)
+            elif (tuple(buf.shape) != (B, c, H, W) or buf.dtype != torch.float32 or buf.device != dev or not buf.is_contiguous()):
+                raise BtsHipError("BtsModel.output_buffers[%d] must be a contiguous float32 [%d,%d,%d,%d] tensor on %s, got %s %s on %s"
+                                  % (i, B, c, H, W, dev, tuple(buf.shape), buf.dtype, buf.device))
+            res.append(buf)
+        return res
 
     def train(self, mode: bool = True):
         # a mode switch is where a training loop hands weights over to evaluation (bts_main.py:193-275 evaluates every
@@ -617,6 +658,14 @@ class BtsModel(nn.Module):
         return super().train(mode)
 
     def forward(self, x, focal):
+        # this model's launch declaration (fill_frames, precision) holds for every kernel launch of the call: a
+        # thread-local scope, so two models -- or two DataParallel replicas -- never see each other's setting
+        if isinstance(x, torch.Tensor) and x.dim() == 4 and not ops.launch_config_active():
+            with ops.model_launch_config(self, x.shape[0]):
+                return self._forward(x, focal)
+        return self._forward(x, focal)
+
+    def _forward(self, x, focal):
         if self.training and self.native_encoder and isinstance(x, torch.Tensor) and x.is_cuda:
             # training step: encoder + decoder as one autograd graph on the HIP kernels (bts_amd/train.py)
             enc_fwd = train.resnet_encoder_forward if isinstance(self.encoder.base_model, encoders.ResNet) \
@@ -631,14 +680,13 @@ class BtsModel(nn.Module):
         while S > 1 and B % S:              # largest divisor of B not above the requested count
             S -= 1
         if S <= 1:
-            return self._forward_native(x, focal, 0)
+            return self._forward_native(x, focal, 0, outs=self._result_tensors(B, H, W, x.device) if self.output_buffers else None)
         # Frames are independent in eval mode (bts.py:223-293 has no cross-sample op), so the batch runs as S
         # concurrent sub-batches, each on its own stream with its own NHWC workspace and writing its slice of
         # the full-batch outputs: the under-filled launches of one (deep encoder layers, tile-quantisation
         # tails) overlap the other's kernels.  Per-frame results are bit-identical to the single-stream path.
         dev = x.device
-        nf16 = self.decoder.num_features // 16
-        full = [torch.empty((B, c, H, W), dtype=torch.float32, device=dev) for c in (1, 1, 1, 1, 1, nf16)]
+        full = self._result_tensors(B, H, W, dev)
         streams = _SIDE_STREAMS.setdefault(str(dev), [])        # per device, process-wide (not module state: a module
         while len(streams) < S:                                  # holding Stream objects cannot be deep-copied / saved)
             streams.append(torch.cuda.Stream(dev))
@@ -646,7 +694,7 @@ class BtsModel(nn.Module):
         dec_ws.max_entries = max(dec_ws.max_entries, 2 * S)
         cur = torch.cuda.current_stream(dev)
         b = B // S
-        mins = []
+        mins = torch.empty((S, 3), dtype=torch.float32, device=dev)      # per-stream abs_min triples, written by the kernels
         focal_d = focal.to(device=dev) if isinstance(focal, torch.Tensor) else focal
         for i in range(S):
             st = streams[i]
@@ -654,11 +702,9 @@ class BtsModel(nn.Module):
             with torch.cuda.stream(st):
                 lo, hi = i * b, (i + 1) * b
                 self._forward_native(x[lo:hi], focal_d[lo:hi] if isinstance(focal_d, torch.Tensor) else focal_d, i,
-                                     outs=[t[lo:hi] for t in full])
-                dec = self.decoder
-                mins.append(torch.stack([dec.lpg8x8.abs_min, dec.lpg4x4.abs_min, dec.lpg2x2.abs_min]))
+                                     outs=[t[lo:hi] for t in full], abs_mins=mins[i])
         for i in range(S):
             cur.wait_stream(streams[i])
-        am = torch.stack(mins).min(dim=0).values                     # abs_min over the whole batch (bts.py:167)
+        am = mins.min(dim=0).values                                   # abs_min over the whole batch (bts.py:167); NaN propagates
         self.decoder.lpg8x8.abs_min, self.decoder.lpg4x4.abs_min, self.decoder.lpg2x2.abs_min = am[0], am[1], am[2]
         return tuple(full)

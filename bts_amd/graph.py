@@ -81,7 +81,9 @@ class GraphedModel(torch.nn.Module):
         if self.model.training or not image.is_cuda:
             return self.model(image, focal)
         fshape = tuple(focal.shape) if isinstance(focal, torch.Tensor) else None
-        key = (tuple(image.shape), str(image.device), str(image.dtype), fshape)
+        # a capture bakes in the model's launch declaration (fill_frames by the batch unless pinned, precision)
+        key = (tuple(image.shape), str(image.device), str(image.dtype), fshape,
+               getattr(self.model, "fill_frames", None), getattr(self.model, "conv_precision", 0))
         entry = self._graphs.get(key)
         if entry is not None and entry.fingerprint != self._fingerprint():
             self._drop(key)                         # weights changed since capture: the graph points at stale packs

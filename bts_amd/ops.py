@@ -6,6 +6,7 @@ Every function requires CUDA(ROCm) fp32 tensors and raises otherwise -- no CPU f
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -425,38 +426,73 @@ def bn_affine(weight, bias, mean, var, eps: float):
     return scale, shift
 
 
-# conv precision for every conv_forward call: 0 = fp32-input MFMA (default), 1 = fp32 emulated on the bf16 matrix
-# cores (bts_conv_desc.precision); set_conv_precision() switches the whole model, e.g. for an A/B bench
-_conv_precision = 0
+# ---- per-call launch configuration -----------------------------------------------------------------------------------
+# Two facts about a convolution launch belong to the CALLER, not to the process: the arithmetic of the contraction
+# (bts_conv_desc.precision: 0 = fp32-input MFMA, 1 = fp32 emulated on the bf16 matrix cores) and the number of frames
+# the caller expects to share the chip (bts_conv_desc.fill_frames, which sizes split-K and the tile family; 0 = the
+# library default of 8).  Both change output BITS (fp32 summation order / product rounding), so two models in one
+# process must be able to hold different values: they live in a thread-local scope that a model opens around its own
+# forward (``BtsModel.fill_frames`` / ``BtsModel.conv_precision``, bts_amd/bts.py) -- there is no process-wide setter.
+# Code that calls conv_forward directly (tests, micro-benchmarks) wraps the calls in ``launch_config(...)``.
+_cfg_tls = threading.local()
+_PRECISIONS = {"fp32": 0, "bf16x3": 1, 0: 0, 1: 1}
 
 
-# bts_conv_desc.fill_frames of every conv_forward call: how many frames the caller expects to share a launch (0 = the
-# library default, 8).  set_fill_frames(1) is the single-frame setting of the reference's test loop.
-_fill_frames = 0
+class launch_config:
+    """``with ops.launch_config(fill_frames=2, precision="bf16x3"): ...`` -- values for every conv_forward call issued by
+    this thread inside the block; ``None`` keeps the enclosing value (library defaults outside any block)."""
+
+    def __init__(self, fill_frames: Optional[int] = None, precision=None):
+        if fill_frames is not None:
+            fill_frames = int(fill_frames)
+            if fill_frames < 0 or fill_frames > 4096:
+                raise BtsHipError("launch_config: fill_frames must be in 0..4096")
+        if precision is not None:
+            if precision not in _PRECISIONS:
+                raise BtsHipError("launch_config: precision must be 'fp32' / 0 or 'bf16x3' / 1")
+            precision = _PRECISIONS[precision]
+        self._new = (fill_frames, precision)
+
+    def __enter__(self):
+        self._prev_raw = getattr(_cfg_tls, "value", None)
+        self._prev = current_launch_config()
+        ff, pr = self._new
+        _cfg_tls.value = (self._prev[0] if ff is None else ff, self._prev[1] if pr is None else pr)
+        return self
+
+    def __exit__(self, *exc):
+        _cfg_tls.value = self._prev_raw
+        return False
 
 
-def set_fill_frames(n: int) -> int:
-    """Frames per launch the split-K / tile choices are sized for (bts_conv_desc.fill_frames): 0 = default (8: batched
-    throughput), 1 = single-frame latency (bts_test.py's loop: 8.8 -> 6.4 ms of GPU time per 352x1216 frame).  The
-    choice never follows the actual batch (a frame's bits must not depend on its neighbours); results of two settings
-    differ by fp32 summation order.  Recorded plans / graphs are aged.  Returns the previous setting."""
-    global _fill_frames
-    n = int(n)
-    if n < 0 or n > 4096:
-        raise BtsHipError("set_fill_frames: expected 0..4096")
-    prev, _fill_frames = _fill_frames, n
-    if prev != n:
-        from . import workspace
-        workspace.invalidate_packs()
-    return prev
+def current_launch_config() -> Tuple[int, int]:
+    """(fill_frames, precision) in force for this thread."""
+    return getattr(_cfg_tls, "value", None) or (0, 0)
 
 
-def set_conv_precision(mode) -> int:
-    """'fp32' / 0 or 'bf16x3' / 1; returns the previous mode."""
-    global _conv_precision
-    prev = _conv_precision
-    _conv_precision = {"fp32": 0, "bf16x3": 1, 0: 0, 1: 1}[mode]
-    return prev
+def launch_config_active() -> bool:
+    """True inside a ``launch_config`` block of this thread (a model called from another model's forward keeps the
+    outer declaration)."""
+    return getattr(_cfg_tls, "value", None) is not None
+
+
+def model_launch_config(module, batch: int) -> "launch_config":
+    """The scope a model opens around its forward: its ``fill_frames`` attribute (None = ``auto_fill_frames(batch)``)
+    and its ``conv_precision`` attribute."""
+    ff = getattr(module, "fill_frames", None)
+    return launch_config(auto_fill_frames(batch) if ff is None else ff, getattr(module, "conv_precision", 0))
+
+
+def auto_fill_frames(batch: int) -> int:
+    """The frames-per-launch declaration a model makes when its ``fill_frames`` attribute is None: a function of the
+    batch it was called with, in three coarse classes (so bits change only between classes, documented in DESIGN 5a):
+    single-frame callers (the reference's own test loop, bts_test.py:127-147: B = 1) get the latency setting; small
+    batches the library default; chip-filling batches the setting bench.py declares."""
+    if batch <= 2:
+        return 2
+    if batch <= 11:
+        return 8
+    return 16
 
 
 def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torch.Tensor, c_out: int,
@@ -525,8 +561,7 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     d.w, d.c_out, d.c_out_pad = w_packed.data_ptr(), c_out, c_out_pad
     keep = []
     d.n_bundles = n_bundles if n_bundles > 1 else 0
-    d.precision = _conv_precision
-    d.fill_frames = _fill_frames
+    d.fill_frames, d.precision = current_launch_config()
     d.n_tail = n_tail
     for j in range(n_tail):
         d.tail_planes[j] = tail_planes[j].data_ptr()

@@ -21,6 +21,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib, workspace
+from . import ops as ops_mod
 from ._lib import BtsHipError, ConvDesc
 
 # entry point -> (BTS_OP_* kind, member name in the bts_op union); argument order = the C prototypes (stream excluded)
@@ -206,7 +207,8 @@ class PlanCache:
         stream = torch.cuda.current_stream(dev).cuda_stream
         origin = model._origin[0]
         fp = (workspace._generation[0], workspace.tensor_fingerprint(origin))
-        key = (tuple(x.shape), str(dev), slot, has_focal, stream)
+        # the launch declaration in force (fill_frames, precision) is baked into every recorded descriptor
+        key = (tuple(x.shape), str(dev), slot, has_focal, stream, ops_mod.current_launch_config())
         entry = self._plans.get(key)
         if entry is not None and entry[1] != fp:
             with self._lock:

@@ -26,15 +26,15 @@ def main():
     ap.add_argument("--frames", type=int, default=50)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--fill-frames", type=int, default=0,
-                    help="ops.set_fill_frames: 0 = library default (8 frames per launch), 1 = single-frame mode")
+                    help="pin BtsModel.fill_frames; 0 = the model's default (by the batch of the call: B <= 2 -> 2, B <= 11 -> 8, else 16)")
     a = ap.parse_args()
     import bench
     from bts_amd import ops, synth
-    ops.set_fill_frames(a.fill_frames)
     from bts_amd.graph import GraphedModel
     params = bench.Params(a.encoder, 512, 80.0, "kitti")
     model = bench.build_model(params, torch.device("cuda"), seed=0)
     model.sub_batches = 1 if a.batch == 1 else 4
+    model.fill_frames = a.fill_frames or None
     img = torch.from_numpy(synth.image_batch(a.batch, a.height, a.width, 1234)).cuda()
     foc = torch.from_numpy(synth.focal_values(a.batch, "kitti", 1234)).cuda()
     out = {"config": "%s, B=%d, 3x%dx%d fp32, %d frames per measurement, fill_frames=%d"

@@ -11,7 +11,6 @@ from bts_amd import synth, ops
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 offset_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 dev = torch.device("cuda", 0)
-ops.set_fill_frames(16)
 params = B.Params("densenet161_bts", 512, 80.0, "kitti")
 models = [B.build_model(params, dev, 0) for _ in range(depth)]
 for m in models[1:]:

@@ -136,7 +136,7 @@ def module_cases():
 OUT_NAMES = ("depth_8x8_scaled", "depth_4x4_scaled", "depth_2x2_scaled", "reduc1x1", "final_depth", "iconv1")
 
 
-def run_decoder(cname, B, H, W, feat_seed):
+def run_decoder(cname, B, H, W, feat_seed, want_den=False):
     enc, max_depth, dataset, _, _ = CONFIGS[cname]
     feat = synth.ENCODER_CHANNELS[enc]
     state = synth.decoder_state(feat, 512, seed=0)
@@ -144,9 +144,20 @@ def run_decoder(cname, B, H, W, feat_seed):
     dec = load_state(ref.bts(p, feat, 512), state)
     feats = synth.encoder_features(feat, B, H, W, seed=feat_seed)
     focal = synth.focal_values(B, dataset, seed=feat_seed)
+    planes = {}
+    hooks = []
+    if want_den:      # the plane equations the reference's own LPG layers receive (bts.py:254, 268, 281)
+        for k, m in ((8, dec.lpg8x8), (4, dec.lpg4x4), (2, dec.lpg2x2)):
+            hooks.append(m.register_forward_pre_hook(lambda mod, args, k=k: planes.__setitem__(k, args[0].detach().clone())))
     with torch.no_grad():
         outs = dec([None] + [t(f) for f in feats[1:]], t(focal))
+    for h in hooks:
+        h.remove()
     absmin = [dec.lpg8x8.abs_min.item(), dec.lpg4x4.abs_min.item(), dec.lpg2x2.abs_min.item()]
+    if want_den:
+        from oracle import bts_oracle as O
+        dens = {k: O.lpg_denominator(planes[k], k).unsqueeze(1).numpy() for k in planes}
+        return [o.numpy() for o in outs], np.asarray(absmin, dtype=np.float32), dens
     return [o.numpy() for o in outs], np.asarray(absmin, dtype=np.float32)
 
 
@@ -166,7 +177,7 @@ N_SAMPLES = 4096
 def decoder_full():
     out = {}
     for cname, (_, _, _, H, W) in CONFIGS.items():
-        outs, absmin = run_decoder(cname, 1, H, W, feat_seed=1234)
+        outs, absmin, dens = run_decoder(cname, 1, H, W, feat_seed=1234, want_den=True)
         rng = np.random.Generator(np.random.PCG64(999))
         for n, o in zip(OUT_NAMES, outs):
             flat = o.reshape(-1)
@@ -177,6 +188,10 @@ def decoder_full():
             out["%s_%s_stats" % (cname, n)] = np.asarray(
                 [fin.min(), fin.max(), fin.astype(np.float64).mean(), np.abs(fin).astype(np.float64).mean(),
                  float(flat.size - fin.size)], dtype=np.float64)
+        # |LPG denominator| of the REFERENCE's own plane equations at the sampled pixels of the three LPG outputs: the
+        # test masks the near-singular samples (|den| <= 2e-3) exactly instead of allowing a fraction to fail
+        for k, n in ((8, OUT_NAMES[0]), (4, OUT_NAMES[1]), (2, OUT_NAMES[2])):
+            out["%s_%s_absden" % (cname, n)] = np.abs(dens[k].reshape(-1)[out["%s_%s_idx" % (cname, n)]]).astype(np.float32)
         out["%s_abs_min" % cname] = absmin
     return out
 
@@ -222,6 +237,10 @@ def decoder_train():
 
 
 def main():
+    if "--only-full" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "decoder_full_samples.npz"), **decoder_full())
+        print("decoder_full_samples.npz", os.path.getsize(os.path.join(HERE, "decoder_full_samples.npz")) // 1024, "KiB")
+        return
     if "--only-train" in sys.argv:
         np.savez_compressed(os.path.join(HERE, "decoder_train.npz"), **decoder_train())
         print("decoder_train.npz", os.path.getsize(os.path.join(HERE, "decoder_train.npz")) // 1024, "KiB")

@@ -82,10 +82,17 @@ def test_one_dying_rank_stops_the_others_promptly(victim):
     assert time.time() - t0 < 120
 
 
-def test_uneven_global_batch_is_rejected():
+def test_uneven_global_batch_is_sharded_padded_and_trimmed():
+    """7 frames over 2 ranks: 4 + 3 (DataParallel.scatter order); the gather pads the short rank and trims again
+    (bts_amd.dist.DepthGather), so the line reports the real global batch and the gather check passes."""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-selftest", "--global-batch", "7"], env=_env(),
                        capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "not a multiple" in r.stderr
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _one_json_line(r.stdout)
+    assert line["global_batch"] == 7 and line["shard"] == [0, 4] and line["batch_per_gpu"] == 4 and line["gather_ok"]
+    bad = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-selftest", "--global-batch", "1"], env=_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "smaller than" in bad.stderr
 
 
 def test_kernel_labels_map_to_rocprof_names():

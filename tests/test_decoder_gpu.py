@@ -45,10 +45,14 @@ def test_decoder_full_size_vs_golden_samples(golden_dir, decoders, cname):
         if n == "iconv1":
             assert (np.abs(gv - val) <= 1e-4 + 1e-3 * np.abs(val)).all()
         else:
-            # near-singular LPG pixels are rare; allow 0.5% of the samples to exceed (they are checked by mask above)
-            rel = np.abs(gv - val) / np.maximum(np.abs(val), 1e-30)
-            frac_bad = float((rel > 1e-4).mean())
-            assert frac_bad <= 0.005, "%s %s: %.3f%% of samples off by >1e-4 (max %g)" % (cname, n, 100 * frac_bad, rel.max())
+            # every sample, no allowance: the three LPG maps mask the near-singular pixels exactly -- the golden stores
+            # |denominator| of the REFERENCE's own plane equations at each sampled pixel (gen_golden.decoder_full)
+            keep = np.ones(idx.shape, dtype=bool)
+            if "%s_%s_absden" % (cname, n) in g.files:
+                keep = g["%s_%s_absden" % (cname, n)] > 2e-3
+                assert keep.mean() > 0.99
+            rel = np.abs(gv - val)[keep] / np.maximum(np.abs(val[keep]), 1e-30)
+            assert rel.max() <= 1e-4, "%s %s: worst sample off by %g (%d of %d above 1e-4)" % (cname, n, rel.max(), int((rel > 1e-4).sum()), rel.size)
         st = g["%s_%s_stats" % (cname, n)]
         fin = flat[np.isfinite(flat)]
         assert abs(fin.astype(np.float64).mean() - st[2]) <= 1e-3 * max(abs(st[3]), 1e-6) + 1e-3 * abs(st[2])
@@ -184,8 +188,7 @@ def test_conv_bf16x3_emulation_is_fp32_accurate(case):
         wp, _, _ = ops.pack_conv_weight(wt.cuda(), c_in_ld=c4)
     errs = {}
     for prec in ("fp32", "bf16x3"):
-        prev = ops.set_conv_precision(prec)
-        try:
+        with ops.launch_config(precision=prec):
             if nchw:
                 y = torch.empty(B, cout, H, W, device="cuda")
                 ops.conv_forward(x2d, B, h, w, wp, cout, k, dil=dil, stride=stride, pad=pad, c_in_ld=c4, act=ops.ACT_ELU,
@@ -197,8 +200,6 @@ def test_conv_bf16x3_emulation_is_fp32_accurate(case):
                                  pad=pad if mode != "subpixel" else None, up=2 if mode == "subpixel" else 1, c_in_ld=c4,
                                  act=ops.ACT_ELU, y2d=y, subpixel=(mode == "subpixel"), c_in_real=cin)
                 got = y.view(B, H, W, cout).permute(0, 3, 1, 2).cpu().double()
-        finally:
-            ops.set_conv_precision(prev)
         errs[prec] = (got - ref).abs().max().item() / ref.abs().max().item()
     print(case, errs)
     assert errs["fp32"] <= 1e-5 and errs["bf16x3"] <= 1e-5, errs
@@ -210,11 +211,12 @@ def test_decoder_bf16x3_mode_vs_oracle(decoders, cname):
     """The whole decoder with every convolution in the bf16x3-emulated mode: same parity bar as the default path."""
     from bts_amd import ops
     ref_outs, inter = oracle_run(cname, 2, 64, 96, 4321)
-    prev = ops.set_conv_precision("bf16x3")
+    dec = decoders[cname]
+    dec.conv_precision = "bf16x3"
     try:
-        got = hip_run(decoders[cname], cname, 2, 64, 96, 4321)
+        got = hip_run(dec, cname, 2, 64, 96, 4321)
     finally:
-        ops.set_conv_precision(prev)
+        dec.conv_precision = "fp32"
     rep = check_outputs(got, ref_outs, inter, what=cname + " small / bf16x3")
     print(cname, "bf16x3 max-rel:", rep)
 
@@ -235,12 +237,9 @@ def test_conv_bf16x3_wide_dynamic_range():
     wp, _, _ = ops.pack_conv_weight(wt.cuda())
     worst = {}
     for prec in ("fp32", "bf16x3"):
-        prev = ops.set_conv_precision(prec)
-        try:
+        with ops.launch_config(precision=prec):
             y = torch.empty(B * h * w, cout, device="cuda")
             ops.conv_forward(x2d, B, h, w, wp, cout, 3, y2d=y)
-        finally:
-            ops.set_conv_precision(prev)
         got = y.view(B, h, w, cout).permute(0, 3, 1, 2).cpu().double()
         worst[prec] = ((got - ref).abs() / mag).max().item()
     print("error / sum|terms|:", worst)

@@ -59,17 +59,31 @@ def _worker(rank, world, port, out_dir):
             return [torch.cat([p[j] for p in per]) for j in range(6)]
 
         outs = run_frames(lo, hi)
-        # uneven shards: pad to the max shard for the fixed-size all_gather_into_tensor, then trim
-        bmax = (GB + world - 1) // world
-        padded = [torch.cat([o, torch.zeros((bmax - o.shape[0],) + tuple(o.shape[1:]))]) for o in outs[:5]]
-        gathered, work = bdist.all_gather_depths(padded, 5, async_op=True)
+        # uneven shards (2 + 1 frames): the library pads to ceil(G / world) frames for the fixed-size
+        # all_gather_into_tensor and trims the pad frames again -- DataParallel.scatter / the reference's
+        # no-evenly-divisible sampler semantics (distributed_sampler_no_evenly_divisible.py:62), no duplicated frame
+        gathered, work = bdist.all_gather_depths(outs, 5, async_op=True, global_batch=GB)
         work.wait()
-        maps = bdist.unshard_depths(gathered)
-        keep = []
-        for r in range(world):
-            a, b = bdist.shard_range(GB, r, world)
-            keep += list(range(r * bmax, r * bmax + (b - a)))
-        maps = [mm[keep] for mm in maps]
+        assert tuple(gathered.shape[:3]) == (world, 5, 2)
+        maps = bdist.unshard_depths(gathered, GB)
+        # persistent buffers: a DepthGather allocates once; the model writes its maps straight into the send buffer
+        # (BtsModel.output_buffers = dg.outputs(slot)), two slots alternate so a collective may still read slot i while
+        # step i+1 fills the other one
+        dg = bdist.DepthGather(5, 2, H, W, "cpu", slots=2)
+        ptrs = [(p.data_ptr(), g.data_ptr()) for p, g in zip(dg.packed, dg.gathered)]
+        for stepno in range(4):
+            sl = stepno % 2
+            views = dg.outputs(sl, hi - lo)
+            assert all(v.is_contiguous() and tuple(v.shape) == (hi - lo, 1, H, W) for v in views)
+            for v, o in zip(views, outs):
+                v.copy_(o + float(stepno))                   # stands for the kernels' stores
+            w = dg.gather(sl, async_op=True)
+            w.wait()
+            got = dg.maps(sl, GB)
+            for i in range(5):
+                assert torch.equal(got[i], maps[i] + float(stepno)), "slot %d, step %d" % (sl, stepno)
+        assert ptrs == [(p.data_ptr(), g.data_ptr()) for p, g in zip(dg.packed, dg.gathered)], "buffers were reallocated"
+        dg.pack(0, dg.outputs(0, hi - lo))                   # already in place: no copy, no error
         # online-eval accumulator (9 error sums + count, bts_main.py:258-260) and the strided eval sharding
         acc = torch.tensor([float(rank + 1)] * 9 + [float(len(bdist.shard_indices(7, rank, world)))])
         bdist.all_reduce_eval_measures(acc)
@@ -80,6 +94,17 @@ def _worker(rank, world, port, out_dir):
         fake_dec = SimpleNamespace(lpg8x8=lp(0.5 + rank), lpg4x4=lp(3.0 - rank), lpg2x2=lp(0.25))
         am, _ = bdist.all_reduce_abs_min(fake_dec)
         assert am.tolist() == [0.5, 3.0 - (world - 1), 0.25] and fake_dec.lpg4x4.abs_min.item() == 3.0 - (world - 1)
+        # a NaN on ONE rank must come out as NaN on EVERY rank (bts.py:167's min() is NaN as soon as one denominator is;
+        # ReduceOp.MIN's own NaN behaviour is the backend's business): it travels as -1
+        nan_dec = SimpleNamespace(lpg8x8=lp(float("nan") if rank == world - 1 else 0.5), lpg4x4=lp(1.0 + rank), lpg2x2=lp(float("nan")))
+        am, _ = bdist.all_reduce_abs_min(nan_dec)
+        assert torch.isnan(am[0]) and am[1].item() == 1.0 and torch.isnan(am[2])
+        assert torch.isnan(nan_dec.lpg8x8.abs_min) and nan_dec.lpg4x4.abs_min.item() == 1.0
+        am, w = bdist.all_reduce_abs_min(SimpleNamespace(lpg8x8=lp(float("nan") if rank == 0 else 2.0), lpg4x4=lp(4.0), lpg2x2=lp(5.0)),
+                                         async_op=True)
+        w.wait()
+        am = bdist.decode_abs_min(am)
+        assert torch.isnan(am[0]) and am[1:].tolist() == [4.0, 5.0]
         if rank == 0:
             ref = run_frames(0, GB)
             for i in range(5):
@@ -123,3 +148,11 @@ def test_single_process_paths_are_noops():
     assert work is None and tuple(g.shape) == (1, 5, 2, 1, 4, 4)
     maps = bdist.unshard_depths(g)
     assert len(maps) == 5 and all(torch.equal(maps[i], outs[i]) for i in range(5))
+    g2, _ = bdist.all_gather_depths(outs, 5)                    # persistent: the second slot, then the first again
+    g3, _ = bdist.all_gather_depths(outs, 5)
+    assert g2.data_ptr() != g.data_ptr() and g3.data_ptr() == g.data_ptr()
+    from types import SimpleNamespace
+    dec = SimpleNamespace(**{n: SimpleNamespace(abs_min=torch.tensor(v)) for n, v in
+                             (("lpg8x8", float("nan")), ("lpg4x4", 0.5), ("lpg2x2", 2.0))})
+    am, _ = bdist.all_reduce_abs_min(dec)
+    assert torch.isnan(am[0]) and am[1:].tolist() == [0.5, 2.0] and torch.isnan(dec.lpg8x8.abs_min)

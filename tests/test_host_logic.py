@@ -304,3 +304,38 @@ def test_block3_kernel_choices_need_a_declaration_above_the_default():
     for fill in (0, 1, 16):
         assert _plan(1, 88, 304, 240, 192, 1, fill)[0] & 15 == 3
         assert _plan(1, 88, 304, 192, 48, 3, fill)[0] & 15 == 1
+
+
+def test_launch_config_is_a_thread_local_scope():
+    """ops.launch_config: the (fill_frames, precision) declaration of a forward is scoped to the calling thread and
+    nests; outside any scope the library defaults apply.  A model's default (fill_frames None) follows the batch of
+    the call in three classes: single frames (bts_test.py's loop) -> 2, small batches -> the library default 8,
+    chip-filling batches -> 16."""
+    import threading
+    from types import SimpleNamespace
+    from bts_amd import ops
+    assert ops.current_launch_config() == (0, 0) and not ops.launch_config_active()
+    seen = {}
+
+    def other():
+        seen["other"] = (ops.current_launch_config(), ops.launch_config_active())
+
+    with ops.launch_config(fill_frames=2, precision="bf16x3"):
+        assert ops.current_launch_config() == (2, 1) and ops.launch_config_active()
+        th = threading.Thread(target=other)
+        th.start()
+        th.join()
+        with ops.launch_config(precision="fp32"):
+            assert ops.current_launch_config() == (2, 0)
+        assert ops.current_launch_config() == (2, 1)
+    assert seen["other"] == ((0, 0), False)
+    assert ops.current_launch_config() == (0, 0) and not ops.launch_config_active()
+    assert [ops.auto_fill_frames(b) for b in (1, 2, 3, 4, 8, 11, 12, 16, 64)] == [2, 2, 8, 8, 8, 8, 16, 16, 16]
+    with ops.model_launch_config(SimpleNamespace(fill_frames=None, conv_precision="fp32"), 1):
+        assert ops.current_launch_config() == (2, 0)
+    with ops.model_launch_config(SimpleNamespace(fill_frames=5, conv_precision="bf16x3"), 16):
+        assert ops.current_launch_config() == (5, 1)
+    for bad in (dict(fill_frames=-1), dict(fill_frames=5000), dict(precision="fp16")):
+        with pytest.raises(ops.BtsHipError):
+            ops.launch_config(**bad)
+    assert not hasattr(ops, "set_fill_frames") and not hasattr(ops, "set_conv_precision")
