@@ -109,11 +109,13 @@ def trace_to_rocprof_name(kernel):
     m = re.match(r"conv1x1_kernel<(\d+),(\d+)>", kernel)
     if m:
         return r"conv1x1_kernel<%s,%s(,true|,false)?>" % (m.group(1), m.group(2))      # 3rd parameter: single weight buffer
-    m = re.match(r"conv_halo_kernel<(\d+),k(\d),(nhwc|nchw)(,tail)?(,w8)?>", kernel)
+    m = re.match(r"conv_halo_kernel<(\d+),k(\d),(nhwc|nchw)(,tail)?(,w8)?(,dil)?>", kernel)
     if m:
         wm = "8" if m.group(5) else (r"\d+" if m.group(1) != "48" else "4")      # the 48-wide tile has a 4- and an 8-wave variant
-        return r"conv_halo_kernel<%s,%s,\d+,\d+,%s,%s,%s(,true|,false)?>" % (m.group(1), wm, m.group(2), "true" if m.group(3) == "nchw" else "false",
-                                                                            "true" if m.group(4) else "false")      # 8th: single weight buffer
+        # 8th parameter: single weight buffer; 9th: dilation of the tile (1, or 3 / 6 / 12 for the dilated ASPP tiles)
+        return r"conv_halo_kernel<%s,%s,\d+,\d+,%s,%s,%s(,true|,false)?%s>" % (
+            m.group(1), wm, m.group(2), "true" if m.group(3) == "nchw" else "false", "true" if m.group(4) else "false",
+            r",(3|6|12)" if m.group(6) else r"(,1)?")
     return None
 
 

@@ -48,6 +48,9 @@ struct ConvKnobs {
     int halo48_w8; long halo48_w8_below;                   // BTS_CONV_HALO48_W8 (0 = never) / _BELOW: 8-wave 48-wide halo tile for declared launches below this many workgroups (default: all)
     long halo_fill;                                        // BTS_CONV_HALO_FILL: declared-launch workgroups from which the halo kernel replaces split-K (200)
     int fill_frames;                                       // BTS_CONV_FILL_FRAMES: default of bts_conv_desc.fill_frames (8)
+    int halo_emu;                                          // BTS_CONV_HALO_EMU: 1 (default) = precision-1 launches with pre-split weights take the bf16x3 halo-tile kernel where eligible, 0 = row-tiled emulation (A/B)
+    int halo_dil;                                          // BTS_CONV_HALO_DIL: 1 (default) = the dilation-3 3x3 convolution (ASPP daspp_3) on the dilated halo tile, 2 = also dilation 6 / 12, 0 = none (row-tiled kernel with tap skipping)
+    int stagger;                                           // BTS_CONV_STAGGER: 1 (default) = the eight-wave 48-wide halo tile staggers the staging block of waves 4..7 against their SIMD partners 0..3 (A/B)
     int halo;                                              // BTS_CONV_HALO: 0 off, 1 = halo-tile kernel where eligible unless split-K applies, 2 = also instead of split-K.  Default 1: on the deep 22x76 maps a frame has only 15 spatial tiles, so at batch 1 split-K fills the chip 7x better (53 vs 16 us per layer), and the choice may not depend on the batch (a frame's bits must not)
 };
 inline long env_long(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
@@ -60,6 +63,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 150),
                                 (int)env_long("BTS_CONV_1X1_SB", 1), (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), (int)env_long("BTS_CONV_HALO_SB", 1), (int)env_long("BTS_CONV_HALO48_W8", 1), env_long("BTS_CONV_HALO48_W8_BELOW", 1L << 40), env_long("BTS_CONV_HALO_FILL", 200),
                                 (int)(env_long("BTS_CONV_FILL_FRAMES", 8) > 0 ? env_long("BTS_CONV_FILL_FRAMES", 8) : 8),
+                                (int)env_long("BTS_CONV_HALO_EMU", 1), (int)env_long("BTS_CONV_HALO_DIL", 1), (int)env_long("BTS_CONV_STAGGER", 1),
                                 (int)env_long("BTS_CONV_HALO", 1)};
     return k;
 }
@@ -100,6 +104,8 @@ struct ConvArgs {
     int fill_frames;                         // frames assumed to share a launch (bts_conv_desc.fill_frames, resolved)
     int halo_single_a;                       // halo-tile kernel: one channel chunk, one A buffer (set by launch_halo)
     int tapskip;                             // 1: a tile skips the taps that fall outside the map for ALL of its pixels (tile_tapmask)
+    const void* w_split;                     // precision 1: weights pre-split into bf16 planes [classes][3][c_out_pad][k_pad] (bts_conv_desc.w_split) or null
+    int stagger;                             // halo-tile kernel, eight-wave 48-wide tile: waves 4..7 stage half a step after their SIMD partners 0..3 (set by launch_halo)
 };
 
 // Taps of a ksize x ksize convolution that can touch the map for at least one pixel of the row tile [m0, m0 + bm) -- a
@@ -743,6 +749,7 @@ struct ConvChoice { int kind, bm, bn, ksplit; long ksteps_issued = 0, ksteps_den
 thread_local ConvChoice* g_dry = nullptr;
 
 #include "conv_halo.inc"
+#include "conv_halo_emu.inc"
 #include "conv_1x1.inc"
 #include "conv_stem.inc"
 
@@ -912,6 +919,7 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
     if ((d->e1_scale && !d->e1_shift) || (d->e2_scale && !d->e2_shift)) return BTS_ERR_INVALID;
     if (!d->y_nchw && d->y_pix_stride < d->c_out) return BTS_ERR_INVALID;
     if (d->act < 0 || d->act > 3) return BTS_ERR_INVALID;
+    if (d->w_split && ((uintptr_t)d->w_split & 15)) return BTS_ERR_INVALID;
     // the kernel addresses both operands with 32-bit element offsets
     if ((double)d->B * d->h_in * d->w_in * (double)d->x_pix_stride >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
     if ((double)d->c_out_pad * (double)d->k_pad * (d->subpixel ? 4.0 : 1.0) >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
@@ -963,7 +971,7 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
         if ((double)d->n_bundles * d->c_out_pad * (double)d->k_pad >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
         a.n_classes = d->n_bundles; a.bundled = 1;
     } else if (d->n_bundles < 0) return BTS_ERR_INVALID;
-    a.ksplit = 1; a.its_per_split = 0; a.ws_ld = 0; a.tapskip = 0; a.halo_single_a = 0;
+    a.ksplit = 1; a.its_per_split = 0; a.ws_ld = 0; a.tapskip = 0; a.halo_single_a = 0; a.stagger = 0; a.w_split = d->w_split;
     a.ws = d->splitk_ws;
     const long wsf = d->splitk_ws ? d->splitk_ws_floats : 0;
     if (d->splitk_ws && (((uintptr_t)d->splitk_ws & 15) || d->splitk_ws_floats < 0)) return BTS_ERR_INVALID;
@@ -983,6 +991,17 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
     }
     if (prec == 1) {
         if (bn == 48) bn = 64;                       // the 16x16x4 48-wide tile has no bf16x3 twin: pad to 64
+        // stride-1 3x3 / sub-pixel 2x2 convolutions on maps that tile well, whole 32-channel chunks, pre-split weights:
+        // the bf16x3 halo-tile kernel (conv_halo_emu.inc); same geometry-only gating as the fp32 halo kernel below
+        if (knobs().halo && knobs().halo_emu && (bn == 128 || bn == 64) && halo_emu_eligible(a, nchw)) {
+            ConvArgs probe = a;
+            probe.n_ntiles = (a.c_out + bn - 1) / bn;
+            const long halo_wgs = (long)a.fill_frames * ((a.H + 3) / 4) * ((a.W + 31) / 32) * probe.n_ntiles * a.n_classes;
+            if (knobs().halo >= 2 || split_factor(probe, wsf) <= 1 || halo_wgs >= knobs().halo_fill) {
+                if (a.subpix) return bn == 128 ? launch_halo_emu<128, 2>(a, s) : launch_halo_emu<64, 2>(a, s);
+                return bn == 128 ? launch_halo_emu<128, 3>(a, s) : launch_halo_emu<64, 3>(a, s);
+            }
+        }
         // LDS buffering: the planes take 6 B per element, and with ONE buffer per workgroup (two barriers per K-step,
         // the other resident workgroup fills the gaps) every tile runs faster than double-buffered with fewer
         // workgroups per CU (total over the decoder layers 134.7 vs 126.6 TFLOP/s-equivalent).  BTS_CONV_EMU_SB=0 = double.
@@ -1040,6 +1059,13 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
                 if (bn == 128) return knobs().halo_sb ? launch_halo<128, 4, 2, 32, 2, false, true>(a, nchw, s) : launch_halo<128, 4, 2, 32, 2>(a, nchw, s);
                 if (bn == 64) return launch_halo<64, 4, 2, 32, 2>(a, nchw, s);
                 if (bn == 32) return knobs().halo_sb ? launch_halo<32, 4, 1, 32, 2, false, true>(a, nchw, s) : launch_halo<32, 4, 1, 32, 2>(a, nchw, s);
+            } else if (a.dil != 1) {
+                // dilated halo tiles (ASPP branches, c_out 128): one eight-wave workgroup per CU, single weight buffer
+                if (bn == 128 && !nchw) {
+                    if (a.dil == 3) return launch_halo<128, 4, 2, 32, 3, false, true, 3>(a, nchw, s);
+                    if (a.dil == 6) return launch_halo<128, 4, 2, 32, 3, false, true, 6>(a, nchw, s);
+                    if (a.dil == 12) return launch_halo<128, 4, 2, 32, 3, false, true, 12>(a, nchw, s);
+                }
             } else {
                 if (bn == 128) return knobs().halo_sb ? launch_halo<128, 4, 2, 32, 3, false, true>(a, nchw, s) : launch_halo<128, 4, 2, 32, 3>(a, nchw, s);
                 if (bn == 64) return launch_halo<64, 4, 2, 32, 3>(a, nchw, s);

@@ -495,6 +495,20 @@ def auto_fill_frames(batch: int) -> int:
     return 16
 
 
+def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
+    """The emulated mode's three-way truncation split of a float32 tensor, done offline: returns int16 [.., 3, R, K] for a
+    [.., R, K] input -- plane 0 = top 16 bits of w, plane 1 = top 16 bits of (w - plane 0), plane 2 = top 16 bits of the
+    remainder (both subtractions are exact in fp32; w - (h + m + l) <= 2^-24 |w|).  Bit for bit what the kernels' own
+    split_store does to an operand on its way to LDS (csrc/conv_mfma.hip)."""
+    _need(w, "split_bf16x3")
+    hi = w.view(torch.int32) & -65536
+    r1 = w - hi.view(torch.float32)
+    mid = r1.view(torch.int32) & -65536
+    lo = (r1 - mid.view(torch.float32)).view(torch.int32) & -65536
+    planes = torch.stack([hi, mid, lo], dim=-3)
+    return (planes >> 16).to(torch.int16).contiguous()
+
+
 def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torch.Tensor, c_out: int,
                  ksize: int, dil: int = 1, up: int = 1, c_in_ld: Optional[int] = None,
                  pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_relu: bool = False,
@@ -562,6 +576,15 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     keep = []
     d.n_bundles = n_bundles if n_bundles > 1 else 0
     d.fill_frames, d.precision = current_launch_config()
+    if d.precision == 1 and n_bundles <= 1 and not n_tail:
+        # weights pre-split into bf16 planes for the emulated mode's halo-tile kernel (LDS-DMA of plain bytes); made once
+        # per packed weight tensor and kept on it
+        ws3 = getattr(w_packed, "_bts_split3", None)
+        if ws3 is None:
+            ws3 = split_bf16x3(w_packed)
+            w_packed._bts_split3 = ws3
+        keep.append(ws3)
+        d.w_split = ws3.data_ptr()
     d.n_tail = n_tail
     for j in range(n_tail):
         d.tail_planes[j] = tail_planes[j].data_ptr()
@@ -620,13 +643,15 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         bm, bn, kind = C.c_int(0), C.c_int(0), C.c_int(0)
         _lib.load().bts_conv_plan_f32(C.byref(d), C.byref(bm), C.byref(bn), C.byref(kind))
         lay = "nchw" if y_nchw is not None else "nhwc"
-        if (kind.value & 15) == 4:
+        if (kind.value & 15) == 5:
+            variant = "conv_halo_emu_kernel<%d,k%d>" % (bn.value, 2 if subpixel else 3)
+        elif (kind.value & 15) == 4:
             variant = "conv_stem_kernel<%d>" % bn.value
         elif (kind.value & 15) == 3:
             variant = "conv1x1_kernel<%d,%d>" % (bn.value, bm.value // 32)      # <BN, WM>: rows = 32 * WM, as rocprofv3 names it
         elif kind.value & 15:
-            variant = "conv_halo_kernel<%d,k%d,%s%s%s>" % (bn.value, 2 if subpixel else 3, lay, ",tail" if (kind.value & 15) == 2 else "",
-                                                          ",w8" if kind.value & 32 else "")
+            variant = "conv_halo_kernel<%d,k%d,%s%s%s%s>" % (bn.value, 2 if subpixel else 3, lay, ",tail" if (kind.value & 15) == 2 else "",
+                                                            ",w8" if kind.value & 32 else "", ",dil" if kind.value & 64 else "")
         else:
             variant = "conv_fwd_kernel<%d,%d,%s%s>" % (bm.value, bn.value, lay, ",splitk" if kind.value & 16 else "")
     xflops = 2.0 * npix_out * c_out * (c_in_ld if n_bundles > 1 else cin) * taps

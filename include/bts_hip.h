@@ -192,6 +192,12 @@ typedef struct bts_conv_desc {
                                 from the split-K kernels to the wide 1x1 tile and the halo kernel -- choices that would cost a
                                 single-frame caller 45 % if they were tied to the default.  Results of different fill_frames
                                 differ in summation order (fp32 rounding)                                                  */
+    const void* w_split;       /* optional, precision = 1 only: the packed weights `w` pre-split into three bf16 planes --
+                                [classes][3][c_out_pad][k_pad] bf16 (classes = 4 for sub-pixel, else 1), plane 0 = the top 16
+                                bits of w, plane 1 = the top 16 bits of (w - plane 0), plane 2 = the top 16 bits of the rest
+                                (the kernels' own truncation split; bts_amd/ops.py:split_bf16x3).  With it the halo-tile
+                                kernel of the emulated mode streams weight tiles global -> LDS by LDS-DMA; NULL = the
+                                row-tiled kernel splits `w` on the fly.  16-byte aligned.                                  */
 } bts_conv_desc;
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);

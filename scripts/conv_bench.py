@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--set", default="dec", choices=["dec", "enc", "all"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"])
+    ap.add_argument("--fill-frames", type=int, default=16)
     a = ap.parse_args()
     B = a.batch
     tot_ms = tot_fl = 0.0
@@ -54,13 +56,14 @@ def main():
         wp, cop, kp = ops.pack_upconv_subpixel(wt) if sub else ops.pack_conv_weight(wt)
         y = torch.empty(B * h * up * w * up, cout, device="cuda")
         run = lambda: ops.conv_forward(x, B, h, w, wp, cout, k, dil=dil, up=up, act=ops.ACT_ELU, y2d=y, subpixel=sub)
-        run()
-        torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        best = 1e9
-        for _ in range(a.reps):
-            s.record(); run(); e.record(); torch.cuda.synchronize()
-            best = min(best, s.elapsed_time(e))
+        with ops.launch_config(fill_frames=a.fill_frames, precision=a.precision):
+            run()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = 1e9
+            for _ in range(a.reps):
+                s.record(); run(); e.record(); torch.cuda.synchronize()
+                best = min(best, s.elapsed_time(e))
         M = B * h * up * w * up
         fl = 2.0 * M * cout * cin * (4 if sub else k * k)       # EXECUTED flops (sub-pixel upconv: 4 taps per output)
         tot_ms += best

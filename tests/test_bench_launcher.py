@@ -104,11 +104,13 @@ def test_kernel_labels_map_to_rocprof_names():
     seen = ["conv_fwd_kernel<64,128,2,4,32,false,0>", "conv_fwd_kernel<128,48,4,1,16,false,0>",
             "conv_halo_kernel<32,4,1,32,3,true,true,false>", "conv_halo_kernel<128,4,2,32,2,false,false,true>",
             "conv1x1_kernel<192,4,false>", "conv1x1_kernel<192,2,true>", "conv_halo_kernel<48,4,1,16,3,false,false,false>",
-            "conv_halo_kernel<48,8,1,16,3,false,false,false>"]
+            "conv_halo_kernel<48,8,1,16,3,false,false,false>", "conv_halo_kernel<128,4,2,32,3,false,false,true,1>",
+            "conv_halo_kernel<128,4,2,32,3,false,false,true,6>", "conv_halo_kernel<128,4,2,32,3,false,false,true,12>"]
     cases = {"conv_fwd_kernel<64,128,nhwc>": [seen[0]], "conv_fwd_kernel<128,48,nhwc,splitk>": [seen[1]],
              "conv_halo_kernel<32,k3,nchw,tail>": [seen[2]], "conv_halo_kernel<128,k2,nhwc>": [seen[3]],
              "conv1x1_kernel<192,4>": [seen[4]], "conv1x1_kernel<192,2>": [seen[5]],
-             "conv_halo_kernel<48,k3,nhwc>": [seen[6]], "conv_halo_kernel<48,k3,nhwc,w8>": [seen[7]]}
+             "conv_halo_kernel<48,k3,nhwc>": [seen[6]], "conv_halo_kernel<48,k3,nhwc,w8>": [seen[7]],
+             "conv_halo_kernel<128,k3,nhwc>": [seen[8]], "conv_halo_kernel<128,k3,nhwc,dil>": [seen[9], seen[10]]}
     for label, want in cases.items():
         pat = bench.trace_to_rocprof_name(label)
         assert pat is not None, label

@@ -122,3 +122,162 @@ def test_plans_and_graphs_follow_the_launch_declaration():
         r8 = [o.clone() for o in m(img, foc)]
         g8 = gm(img, foc)
         assert all(torch.equal(x, y) for x, y in zip(g8, r8)) and gm.captures == 3
+
+
+# ------------------------------------------------------------------------------- dilated halo tiles (ASPP 3x3, bts.py:73-77)
+@pytest.mark.parametrize("dil,shape", [(3, (2, 44, 152)), (6, (2, 44, 152)), (12, (1, 44, 152)), (3, (1, 46, 150)), (6, (3, 45, 150)),
+                                       (12, (2, 47, 160))])
+def test_dilated_halo_tile_vs_torch_and_row_tiled(dil, shape):
+    """conv_halo_kernel<..., DIL>: the dilated 3x3 of an ASPP branch (BN + ReLU prologue, 256 -> 128, padding = dilation)
+    on LDS-staged tiles whose four output rows lie `dil` apart, so that the input patch has six rows whatever the
+    dilation.  Against torch in fp64 (zero padding of the POST-prologue tensor on all four borders; maps whose height is
+    not a multiple of the 4*dil row group and whose width is not a multiple of 32; several frames) and against the
+    row-tiled kernel (same launch with BTS_CONV_HALO_DIL=0 in a child process: both are exact-f32 fmaf chains in a
+    different K order, so they agree to rounding, not bit for bit); frames are independent (bit-equal alone and in a
+    batch)."""
+    import os, subprocess, sys, tempfile
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_round2_gpu as T
+    if os.environ.get("BTS_CONV_HALO_DIL") != "2":
+        # the library default puts only dilation 3 on the dilated tile (6 / 12 measured slower than the tap-skipping row
+        # tiles): run this test's body in a child process that enables all three
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_round3_gpu as R; "
+                "R.test_dilated_halo_tile_vs_torch_and_row_tiled(%d, %r)" % (
+                    os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), dil, shape))
+        subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BTS_CONV_HALO_DIL="2"))
+        return
+    y, ratio, kern = T._dilated_case(dil, shape)
+    assert kern == "conv_halo_kernel<128,k3,nhwc,dil>", kern
+    B, h, w = shape
+    g = torch.Generator().manual_seed(100 + dil)
+    x = torch.randn((B * h * w, 256), generator=g)
+    wt = torch.randn((128, 256, 3, 3), generator=g) * 0.03
+    ps, pb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    xin = torch.relu(x.double() * ps.double() + pb.double()).reshape(B, h, w, 256).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xin, wt.double(), dilation=dil, padding=dil)
+    got = y.double().reshape(B, h, w, 128).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() / ref.abs().max().item() <= 3e-6
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_round2_gpu as T; "
+            "y, r, k = T._dilated_case(%d, %r); assert k.startswith('conv_fwd_kernel<'), k; torch.save(y, sys.argv[1])" % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), dil, shape))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "y.pt")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, BTS_CONV_HALO_DIL="0"))
+        y_rows = torch.load(out, weights_only=True)
+    assert (y_rows - y).abs().max().item() / y.abs().max().item() <= 3e-6
+    if B > 1:                                   # the last frame alone: same bits
+        from bts_amd import ops
+        wp, _, _ = ops.pack_conv_weight(wt.cuda())
+        y1 = torch.empty((h * w, 128), device="cuda")
+        ops.conv_forward(x[(B - 1) * h * w:].cuda(), 1, h, w, wp, 128, 3, dil=dil, pad=dil, pre=(ps.cuda(), pb.cuda()), pre_relu=True, y2d=y1)
+        assert torch.equal(y1.cpu(), y[(B - 1) * h * w:])
+
+
+def test_dilated_halo_tile_is_chosen_by_geometry_only():
+    """Which dilated 3x3 convolutions take the dilated halo tile by default: dilation 3 with 128 outputs on maps whose
+    4*dil row groups and 32-pixel columns fill >= 80 % of the tile grid (the 44x152 KITTI map: yes; the 52x68 NYU map: no);
+    every other dilation and single-frame launches that split K stay row-tiled."""
+    import ctypes as C
+    from bts_amd import _lib, ops
+    lib = _lib.load()
+
+    def kind(dil, h, w, fill, cout=128, B=1):
+        x = torch.empty((B * h * w, 256), device="cuda")
+        wp, _, _ = ops.pack_conv_weight(torch.zeros((cout, 256, 3, 3), device="cuda"))
+        y = torch.empty((B * h * w, cout), device="cuda")
+        ws = torch.empty(8 * B * h * w * cout, device="cuda")
+        tr = ops.KernelTrace()
+        ops.set_trace(tr)
+        try:
+            with ops.launch_config(fill_frames=fill):
+                ops.conv_forward(x, B, h, w, wp, cout, 3, dil=dil, pad=dil, y2d=y, splitk_ws=ws)
+        finally:
+            ops.set_trace(None)
+        return sorted(tr.summary())[0]
+
+    assert kind(3, 44, 152, 8) == kind(3, 44, 152, 16) == "conv_halo_kernel<128,k3,nhwc,dil>"
+    for d in (6, 12, 18, 24):                                    # 6 / 12: built, measured slower than the tap-skipping row tiles
+        assert kind(d, 44, 152, 8).startswith("conv_fwd_kernel<")
+    assert kind(3, 52, 68, 8).startswith("conv_fwd_kernel<")
+    assert "splitk" in kind(3, 44, 152, 1)                       # single-frame declaration: split-K fills the chip better
+    assert kind(3, 44, 152, 8, cout=64).startswith("conv_fwd_kernel<")
+
+
+# ------------------------------------------------------------------- bf16x3 halo-tile kernel (precision 1, conv_halo_emu.inc)
+@pytest.mark.parametrize("cin,cout,shape,mode,pre", [(64, 128, (2, 44, 152), "conv", True), (448, 256, (1, 44, 152), "conv", False),
+                                                     (192, 48, (2, 88, 304), "conv", True), (128, 64, (1, 45, 150), "conv", True),
+                                                     (128, 128, (2, 44, 152), "subpixel", False), (128, 64, (1, 88, 304), "subpixel", False),
+                                                     (32, 128, (3, 9, 70), "conv", True)])
+def test_bf16x3_halo_tile_vs_fp64_and_fp32_mode(cin, cout, shape, mode, pre):
+    """conv_halo_emu_kernel: stride-1 3x3 / sub-pixel 2x2 convolutions in the fp32-emulated-on-bf16 arithmetic on halo
+    tiles -- input patch split into three bf16 planes once per chunk, weights pre-split offline (ops.split_bf16x3) and
+    streamed by LDS-DMA.  Against torch in fp64 at the fp32-MFMA mode's own error level (both modes reported), ragged
+    right / bottom tiles, prologue + zero padding, ELU epilogue into a strided channel slice, frames independent."""
+    import torch.nn.functional as F
+    from bts_amd import ops
+    B, h, w = shape
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn((B, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(cin * 9.0)
+    ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    xin = torch.relu(x.double() * ps.double().view(1, -1, 1, 1) + pb.double().view(1, -1, 1, 1)) if pre else x.double()
+    sub = mode == "subpixel"
+    if sub:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.elu(F.conv2d(xin, wt.double(), padding=1))
+    H, W = ref.shape[2:]
+    x2d = x.permute(0, 2, 3, 1).reshape(B * h * w, cin).contiguous().cuda()
+    wp = (ops.pack_upconv_subpixel(wt.cuda()) if sub else ops.pack_conv_weight(wt.cuda()))[0]
+    ybuf = torch.zeros((B * H * W, cout + 32), device="cuda")
+    y = ybuf[:, 16:16 + cout]
+
+    def run(prec, xx, bb, out):
+        tr = ops.KernelTrace()
+        ops.set_trace(tr)
+        try:
+            with ops.launch_config(fill_frames=16, precision=prec):
+                ops.conv_forward(xx, bb, h, w, wp, cout, 3, up=2 if sub else 1, act=ops.ACT_ELU, y2d=out, subpixel=sub,
+                                 pre=(ps.cuda(), pb.cuda()) if pre else None, pre_relu=pre)
+        finally:
+            ops.set_trace(None)
+        return sorted(tr.summary())[0]
+
+    errs = {}
+    for prec in ("fp32", "bf16x3"):
+        kern = run(prec, x2d, B, y)
+        if prec == "bf16x3":
+            assert kern == "conv_halo_emu_kernel<%d,k%d>" % (128 if cout >= 128 else 64, 2 if sub else 3), kern
+        got = y.reshape(B, H, W, cout).permute(0, 3, 1, 2).cpu().double()
+        errs[prec] = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert float(ybuf[:, :16].abs().max()) == 0.0 and float(ybuf[:, 16 + cout:].abs().max()) == 0.0     # only the slice is written
+    print((cin, cout, shape, mode), errs)
+    assert errs["fp32"] <= 1e-5 and errs["bf16x3"] <= 1e-5, errs
+    assert errs["bf16x3"] <= 3.0 * errs["fp32"] + 2e-7, errs
+    if B > 1:
+        full = y.clone()
+        y1 = torch.zeros((H * W, cout), device="cuda")
+        run("bf16x3", x2d[(B - 1) * h * w:], 1, y1)
+        assert torch.equal(y1, full[(B - 1) * H * W:])
+
+
+def test_split_bf16x3_matches_the_definition():
+    """ops.split_bf16x3: h + m + l reproduces w to 2^-24 |w|, every piece is a bf16 (16 significant bits kept as the top
+    half of an fp32), and the planes are what a truncation split gives (checked against a NumPy statement)."""
+    from bts_amd import ops
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn((64, 96), generator=g) * torch.pow(10.0, torch.empty((64, 1)).uniform_(-6, 4, generator=g))).contiguous()
+    w[0, :4] = torch.tensor([0.0, -0.0, 1.0, -3.0e-39])
+    planes = ops.split_bf16x3(w.cuda()).cpu()
+    assert planes.shape == (3, 64, 96) and planes.dtype == torch.int16
+    pieces = (planes.to(torch.int32) << 16).view(torch.float32).double()
+    rec = pieces.sum(0)
+    assert ((rec - w.double()).abs() <= 2.0 ** -24 * w.double().abs() + 1e-45).all()
+    wn = w.numpy()
+    hb = wn.view(np.uint32) & 0xffff0000
+    r1 = wn - hb.view(np.float32)
+    mb = r1.view(np.uint32) & 0xffff0000
+    lb = (r1 - mb.view(np.float32)).view(np.uint32) & 0xffff0000
+    want = np.stack([hb, mb, lb]) >> 16
+    assert np.array_equal(planes.numpy().view(np.uint16), want.astype(np.uint16))
+    w4 = torch.randn((4, 32, 64), generator=g).cuda()
+    assert ops.split_bf16x3(w4).shape == (4, 3, 32, 64)
