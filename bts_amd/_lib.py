@@ -21,7 +21,7 @@ SYMBOLS = (
     "bts_reduc_lpg_fwd_f32", "bts_plan_run", "bts_upconv_combine_f32",
 )
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class ConvDesc(C.Structure):

@@ -6,6 +6,7 @@ Every function requires CUDA(ROCm) fp32 tensors and raises otherwise -- no CPU f
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from typing import List, Optional, Sequence, Tuple
 
@@ -465,9 +466,19 @@ class launch_config:
         return False
 
 
+# Outside any launch_config scope the precision is $BTS_CONV_PRECISION (0 / 1, the knob libbts_hip.so itself reads as an
+# override of every descriptor): `BTS_CONV_PRECISION=1 python -m pytest tests -m gpu` runs the WHOLE suite -- module-level
+# ops, models, training forward AND backward (autograd runs the backward outside the model's scope) -- in the emulated
+# arithmetic, pre-split weights included.
+_ENV_PRECISION = 1 if os.environ.get("BTS_CONV_PRECISION", "0").strip() == "1" else 0
+
+
 def current_launch_config() -> Tuple[int, int]:
     """(fill_frames, precision) in force for this thread."""
-    return getattr(_cfg_tls, "value", None) or (0, 0)
+    v = getattr(_cfg_tls, "value", None)
+    if v is None:
+        return (0, _ENV_PRECISION)
+    return (v[0], 1 if _ENV_PRECISION else v[1])
 
 
 def launch_config_active() -> bool:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 11
+#define BTS_HIP_ABI_VERSION 12
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */

@@ -29,9 +29,9 @@ def test_cabi_exports_every_declared_symbol():
 
 def test_conv_desc_layout_matches_header():
     from bts_amd._lib import ConvDesc
-    assert ctypes.sizeof(ConvDesc) == 256
+    assert ctypes.sizeof(ConvDesc) == 264
     assert ConvDesc.w.offset == 56 and ConvDesc.y.offset == 136 and ConvDesc.y_nchw.offset == 152
-    assert ConvDesc.tail_planes.offset == 216 and ConvDesc.n_tail.offset == 248
+    assert ConvDesc.tail_planes.offset == 216 and ConvDesc.n_tail.offset == 248 and ConvDesc.w_split.offset == 256
 
 
 @pytest.mark.parametrize("enc", ["densenet161_bts", "resnext101_bts", "densenet121_bts", "resnet50_bts"])
@@ -232,7 +232,7 @@ def _ksteps(B, h, w, cin, cout, k, dil, pad, fill=0):
     return issued.value, dense.value, bm.value, kind.value
 
 
-@pytest.mark.parametrize("B,h,w,dil", [(2, 44, 152, 24), (2, 44, 152, 18), (1, 44, 152, 3), (3, 52, 68, 24), (1, 13, 17, 24), (2, 11, 19, 6)])
+@pytest.mark.parametrize("B,h,w,dil", [(2, 44, 152, 24), (2, 44, 152, 18), (1, 44, 152, 6), (3, 52, 68, 24), (1, 13, 17, 24), (2, 11, 19, 6), (1, 52, 68, 3)])      # (dilation 3 on 44x152 takes the dilated halo tile)
 def test_tap_skipping_rule_is_a_superset_of_the_taps_a_tile_needs(B, h, w, dil):
     """tile_tapmask (conv_mfma.hip) may only drop a tap that lies in the zero padding for EVERY pixel of the row tile
     (reference: the dilated 3x3 of atrous_conv, bts.py:75-77, padding = dilation).  Brute force over all pixels: the

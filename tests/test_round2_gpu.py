@@ -14,6 +14,8 @@ from oracle import bts_oracle as O
 from parity_util import (CONFIGS, Params, assert_grads_close, build_hip_decoder, check_outputs, grad_error_report,
                          hip_run, make_inputs, oracle_run, t)
 
+from conftest import fp32_only
+
 pytestmark = pytest.mark.gpu
 
 
@@ -312,6 +314,7 @@ def test_config3_rank_shard_b8_through_all_gather():
 
 
 # ------------------------------------------------- configs[4]: the per-GPU training step (B=4, 352x704, DenseNet161)
+@fp32_only
 def test_config5_densenet161_train_step_b4_352x704_vs_cpu():
     """BASELINE configs[4] per-GPU workload: one whole-model DenseNet161 training step (bts_main.py:476-500 protocol)
     at B=4, 352x704 -- encoder + decoder on the HIP kernels -- against the same step on the CPU (torch encoder modules
@@ -518,6 +521,7 @@ def test_planned_forward_equals_eager_and_follows_weight_changes():
 
 
 # --------------------------------------------------------------------------------------------- wide-tile 1x1 kernel
+@fp32_only
 @pytest.mark.parametrize("cin,cout,shape,pre,e1,res", [(96, 192, (2, 44, 152), True, True, False), (240, 192, (1, 88, 304), True, True, False),
                                                        (36, 128, (2, 50, 70), False, False, True), (576, 256, (1, 44, 152), True, True, False),
                                                        (128, 384, (1, 61, 47), False, True, True), (832, 192, (1, 44, 152), True, True, False)])
@@ -687,6 +691,7 @@ def test_fill_frames_1_splits_more_layers_stays_frame_independent_and_close():
 
 
 # --------------------------------------------------------------------------------------------- encoder stem kernel
+@fp32_only
 @pytest.mark.parametrize("cout,shape,cin", [(96, (2, 64, 96), 3), (64, (1, 70, 90), 3), (96, (3, 38, 50), 3), (96, (1, 352, 1216), 3),
                                             (96, (2, 38, 50), 4)])
 def test_stem_kernel_vs_torch(cout, shape, cin):
@@ -786,6 +791,7 @@ def test_tap_skipping_leaves_every_bit_unchanged(dil, shape):
 
 
 # ------------------------------------------------------------------------------ the declaration bench.py runs with
+@fp32_only
 def test_fill_frames_16_block3_on_wide_and_halo_kernels_frame_independent_cpu_parity():
     """fill_frames 16 (what a model left at its default declares from B = 12 on, bench.py's B=16 included): DenseNet block 3 then runs on the wide 1x1 tile and the eight-wave 48-wide
     halo tile instead of the row-tiled / split-K kernels (checked through the launch trace).  At full size (B=16,

@@ -9,6 +9,8 @@ import torch
 from bts_amd import synth
 from parity_util import Params, t
 
+from conftest import fp32_only
+
 pytestmark = pytest.mark.gpu
 
 
@@ -90,6 +92,7 @@ def test_two_models_keep_their_own_launch_declaration():
         assert all(torch.equal(x, y) for x, y in zip(r4, a4)), "B=4 at the default must be the fill_frames=8 path"
 
 
+@fp32_only
 def test_plans_and_graphs_follow_the_launch_declaration():
     """A recorded plan and a captured graph bake the declaration into every descriptor: after ``conv_precision`` or
     ``fill_frames`` changes on the model, neither may replay the old recording (set_conv_precision did not
@@ -125,6 +128,7 @@ def test_plans_and_graphs_follow_the_launch_declaration():
 
 
 # ------------------------------------------------------------------------------- dilated halo tiles (ASPP 3x3, bts.py:73-77)
+@fp32_only
 @pytest.mark.parametrize("dil,shape", [(3, (2, 44, 152)), (6, (2, 44, 152)), (12, (1, 44, 152)), (3, (1, 46, 150)), (6, (3, 45, 150)),
                                        (12, (2, 47, 160))])
 def test_dilated_halo_tile_vs_torch_and_row_tiled(dil, shape):
@@ -173,6 +177,7 @@ def test_dilated_halo_tile_vs_torch_and_row_tiled(dil, shape):
         assert torch.equal(y1.cpu(), y[(B - 1) * h * w:])
 
 
+@fp32_only
 def test_dilated_halo_tile_is_chosen_by_geometry_only():
     """Which dilated 3x3 convolutions take the dilated halo tile by default: dilation 3 with 128 outputs on maps whose
     4*dil row groups and 32-pixel columns fill >= 80 % of the tile grid (the 44x152 KITTI map: yes; the 52x68 NYU map: no);

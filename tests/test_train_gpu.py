@@ -13,6 +13,8 @@ from oracle import bts_oracle as O
 from parity_util import (CONFIGS, TRAIN_CASE, Params, assert_grads_close, check_train_against_golden, grad_error_report,
                          make_inputs, oracle_train_step, t)
 
+from conftest import fp32_only
+
 pytestmark = pytest.mark.gpu
 
 
@@ -250,6 +252,7 @@ def test_train_mode_modules_match_oracle():
     assert (got.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
+@fp32_only
 def test_btsmodel_train_step_densenet121_vs_cpu():
     """One whole-model training step (bts_main.py:476-500 protocol): DenseNet121 encoder + decoder, silog loss,
     backward.  CPU side: the same torch encoder modules + the oracle decoder with autograd, in fp64 (yardstick) and
