@@ -307,8 +307,13 @@ constexpr long chain16_frag_float4s() {
 }
 
 // NT = 16-pixel tiles per wave (4: 64 pixels, all lanes busy in the epilogue; 2: half the registers, more waves)
+// The 2x2 chain (C0 = 64) is compiled for FOUR waves per SIMD (128 VGPRs; the LPG variant spills two dwords): its MFMA,
+// VALU (29 ELU + sigmoid / sin / cos evaluations per 32 pixels) and HBM times are all ~60-80 us at B = 16 and only
+// overlap across waves -- 3 -> 4 waves per SIMD took the fused launch from 204 to 175 us (gpurun_out/r3l).  A register
+// double-buffer that prefetches the next pixel group instead cost occupancy and measured -3 % fused / +13 % stand-alone:
+// dropped.
 template <int C0, int M0, bool FINAL, int NT, int LPGK = 0>
-__global__ __launch_bounds__(512) void reduc16_fwd_kernel(const float* __restrict__ x, long x_pix_stride, long npix,
+__global__ __launch_bounds__(512, (C0 == 64 ? 4 : 1)) void reduc16_fwd_kernel(const float* __restrict__ x, long x_pix_stride, long npix,
                                                           const float4* __restrict__ w_frag, float max_depth,
                                                           int normalize, float* __restrict__ out, const LpgTail lt) {
     static_assert(LPGK == 0 || NT == 2, "the LPG tail expects 32 cells per wave");

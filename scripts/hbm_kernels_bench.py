@@ -53,6 +53,31 @@ def reduc(B, name, H=352, W=1216):
     print("reduc%s B=%3d: %8.1f us  %7.1f GB/s (%4.1f %% of 8 TB/s)  %6.1f TFLOP/s" % (name, B, ms * 1e3, nbytes / ms / 1e6, nbytes / ms / 1e6 / PEAK * 100, 2.0 * npix * macs / ms / 1e9))
 
 
+def reduc_lpg(B, name, H=352, W=1216):
+    """The fused launch of the decoder pipeline: reduction chain -> normalize -> LPG -> /max_depth (+ downsampled plane, abs_min)."""
+    cin, cfirst, k = {"8x8": (128, 128, 8), "4x4": (128, 64, 4), "2x2": (64, 32, 2)}[name]
+    h, w = H // k, W // k
+    npix = B * h * w
+    x = torch.randn(npix, cin, device="cuda")
+    chain = synth.reduc_chain_channels(cin, cfirst, False)
+    ws = [torch.randn(chain[i + 1], chain[i], 1, 1, device="cuda") * 0.1 for i in range(len(chain) - 1)]
+    frag = ops.pack_reduc_weights(ws)
+    depth = torch.empty(B, 1, H, W, device="cuda")
+    ds = torch.empty(npix * 4, device="cuda") if k > 2 else None
+    am = torch.zeros((), device="cuda")
+    ms = timeit(lambda: ops.reduc_lpg_forward(x, B, h, w, cin, cfirst, frag, 80.0, k, depth, ds_out=ds, abs_min=am))
+    nbytes = 4.0 * (x.numel() + depth.numel() + (ds.numel() if ds is not None else 0))
+    macs = sum(chain[i] * chain[i + 1] for i in range(len(chain) - 1))
+    print("reduc_lpg%s B=%3d: %8.1f us  %7.1f GB/s (%4.1f %% of 8 TB/s)  %6.1f TFLOP/s" % (name, B, ms * 1e3, nbytes / ms / 1e6, nbytes / ms / 1e6 / PEAK * 100, 2.0 * npix * macs / ms / 1e9))
+
+
+if "--reduc-only" in sys.argv:
+    for n in ("8x8", "4x4", "2x2"):
+        reduc_lpg(16, n)
+    for n in ("8x8", "4x4", "2x2", "1x1"):
+        reduc(16, n)
+    sys.exit(0)
+
 # calibration: what this device sustains for pure streaming writes / copies (torch elementwise kernels, 1 GiB)
 buf = torch.empty(256 * 1024 * 1024, device="cuda")
 src = torch.randn_like(buf)
@@ -70,3 +95,5 @@ for B in (16, 128):
     lpg(B, 8, ds=False)
     for n in ("8x8", "4x4", "2x2", "1x1"):
         reduc(B, n)
+    for n in ("8x8", "4x4", "2x2"):
+        reduc_lpg(B, n)
