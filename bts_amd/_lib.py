@@ -177,6 +177,26 @@ def load_real():
     return lib
 
 
+TORCH_LIB_PATH = os.path.join(_HERE, "libbts_torch.so")
+_torch_ops = None
+
+
+def load_torch_ops():
+    """``torch.ops.bts_hip``: the TORCH_LIBRARY operator shell over the C ABI (csrc/torch_ops.cpp -> libbts_torch.so:
+    TORCH_CHECK validation, device guard, current stream).  Loaded once; raises loudly if it is not built."""
+    global _torch_ops
+    if _torch_ops is not None:
+        return _torch_ops
+    import torch
+    load_real()                                    # the C ABI library first: libbts_torch.so links against it
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise BtsHipError("bts_amd: %s not found -- build it with `make -C bts_amd/csrc` (or BTS_BINDING=ctypes to bind the "
+                          "C ABI directly)" % TORCH_LIB_PATH)
+    torch.ops.load_library(TORCH_LIB_PATH)
+    _torch_ops = torch.ops.bts_hip
+    return _torch_ops
+
+
 def check(code: int, what: str):
     if code != 0:
         msg = load().bts_hip_error_string(code)

@@ -270,6 +270,17 @@ class local_planar_guidance(nn.Module):
         self.abs_min = None
 
     def forward(self, plane_eq, focal):
+        tops = ops.torch_ops()
+        if tops is not None:
+            # the torch operator: validation, device guard and current stream in the C++ shell, autograd registered on it
+            # (bts_hip::lpg / bts_hip::lpg_backward -- the pair the reference registers as LocalPlanarGuidance /
+            # LocalPlanarGuidanceGrad, local_planar_guidance.cc:31-72, 234-239)
+            ops._need(plane_eq, "local_planar_guidance")
+            box = []
+            ops._op(lambda: box.append(tops.lpg(plane_eq, int(self.upratio))))
+            depth, am = box[0]
+            self.abs_min = am.detach()
+            return depth
         am = torch.empty((), dtype=torch.float32, device=plane_eq.device)
         if torch.is_grad_enabled() and plane_eq.requires_grad:
             depth = ops.LpgFunction.apply(plane_eq, int(self.upratio), am)      # native backward (bts_lpg_bwd_f32)

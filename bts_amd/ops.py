@@ -89,12 +89,60 @@ def _rows2d(t: torch.Tensor, name: str) -> Tuple[int, int]:
     return t.stride(0), t.shape[1]
 
 
+# ------------------------------------------------------------------------------ binding of the hot-path operators
+# The hot-path operators (LPG, reduction_1x1, reduction -> LPG, the fused convolution) are TORCH OPERATORS:
+# torch.ops.bts_hip.* (csrc/torch_ops.cpp, a TORCH_LIBRARY shell over the C ABI -- what the reference's native side does
+# with REGISTER_OP / OpKernel, local_planar_guidance.cc:31-72, 116-156, 234-239).  BTS_BINDING=ctypes binds the C ABI
+# directly instead (A/B, and what a plan recording listens on: bts_amd/plan.py records through the ctypes proxy).
+_BINDING = os.environ.get("BTS_BINDING", "torch").strip().lower()
+_autograd_registered = False
+
+
+def torch_ops():
+    """torch.ops.bts_hip, or None when this call must go through the ctypes binding."""
+    global _autograd_registered
+    if _BINDING != "torch" or _lib.is_recording():
+        return None
+    t = _lib.load_torch_ops()
+    if not _autograd_registered:
+        _autograd_registered = True
+
+        def _setup(ctx, inputs, output):
+            ctx.save_for_backward(inputs[0])
+            ctx.upratio = int(inputs[1])
+
+        def _backward(ctx, grad_depth, grad_abs_min):
+            return t.lpg_backward(ctx.saved_tensors[0], grad_depth.contiguous(), ctx.upratio), None
+
+        torch.library.register_autograd("bts_hip::lpg", _backward, setup_context=_setup)
+    return t
+
+
+def _op(fn):
+    """Run a torch operator; its TORCH_CHECK failures surface as BtsHipError like the ctypes binding's return codes."""
+    try:
+        fn()
+    except BtsHipError:
+        raise
+    except RuntimeError as e:
+        raise BtsHipError(str(e).split("\n")[0]) from None
+    return 0
+
+
 # ------------------------------------------------------------------------------ LPG
 def lpg_forward(plane_eq: torch.Tensor, upratio: int, abs_min: Optional[torch.Tensor] = None) -> torch.Tensor:
     """local_planar_guidance.forward (reference bts.py:149-173): [B,4,h,w] -> [B,h*k,w*k]."""
     _need(plane_eq, "lpg_forward")
     if plane_eq.dim() != 4 or plane_eq.shape[1] != 4:
         raise BtsHipError("lpg_forward: plane_eq must be [B,4,h,w]")
+    tops = torch_ops()
+    if tops is not None:                         # differentiable (autograd registered on bts_hip::lpg)
+        box = []
+        _op(lambda: box.append(tops.lpg(plane_eq, int(upratio))))
+        out, am = box[0]
+        if abs_min is not None:
+            abs_min.copy_(am.detach())
+        return out
     plane_eq = plane_eq.contiguous()
     B, _, h, w = plane_eq.shape
     k = int(upratio)
@@ -222,12 +270,16 @@ def reduc_forward_nhwc(x2d: torch.Tensor, c_in: int, c_first_out: int, w_frag: t
     chain = reduc_chain(c_in, c_first_out)
     macs = sum(ci * (co if co > 0 else (1 if is_final else 3)) for ci, co in chain)
     nbytes = 4.0 * (npix * (c_in + (1 if is_final else 4)) + macs)
+    tops = torch_ops()
+    if tops is not None:
+        run = lambda: _op(lambda: tops.reduction_1x1(x2d, int(c_in), int(c_first_out), w_frag, float(max_depth), bool(is_final),
+                                                     bool(normalize), out))
+    else:
+        run = lambda: _lib.load().bts_reduc_fwd_f32(_ptr(x2d), stride, npix, int(c_in), int(c_first_out),
+                                                    _ptr(w_frag), w_frag.numel(), float(max_depth),
+                                                    int(bool(is_final)), int(bool(normalize)), _ptr(out), _stream(x2d))
     with torch.cuda.device(x2d.device):
-        rc = _launch("reduc_fwd_kernel<%d,%d>" % (c_in, c_first_out), "reduc", 2.0 * npix * macs, nbytes,
-                     lambda: _lib.load().bts_reduc_fwd_f32(_ptr(x2d), stride, npix, int(c_in), int(c_first_out),
-                                                           _ptr(w_frag), w_frag.numel(), float(max_depth),
-                                                           int(bool(is_final)), int(bool(normalize)), _ptr(out),
-                                                           _stream(x2d)))
+        rc = _launch("reduc_fwd_kernel<%d,%d>" % (c_in, c_first_out), "reduc", 2.0 * npix * macs, nbytes, run)
     _lib.check(rc, "bts_reduc_fwd_f32")
     return out
 
@@ -256,12 +308,17 @@ def reduc_lpg_forward(x2d: torch.Tensor, B: int, h: int, w: int, c_in: int, c_fi
     chain = reduc_chain(c_in, c_first_out)
     macs = sum(ci * (co if co > 0 else 3) for ci, co in chain)
     nbytes = 4.0 * (npix * c_in + macs + npix * k * k + (npix * 4 if ds_out is not None else 0))
+    tops = torch_ops()
+    if tops is not None:
+        run = lambda: _op(lambda: tops.reduc_lpg(x2d, B, h, w, int(c_in), int(c_first_out), w_frag, float(max_depth), k,
+                                                 depth_scaled, ds_out, abs_min, plane4))
+    else:
+        run = lambda: _lib.load().bts_reduc_lpg_fwd_f32(_ptr(x2d), stride, B, h, w, int(c_in), int(c_first_out),
+                                                        _ptr(w_frag), w_frag.numel(), float(max_depth), k,
+                                                        _ptr(plane4), _ptr(depth_scaled), _ptr(ds_out),
+                                                        _ptr(abs_min), _stream(x2d))
     with torch.cuda.device(x2d.device):
-        rc = _launch("reduc_lpg_kernel<%d,%d,k%d>" % (c_in, c_first_out, k), "reduc_lpg", 2.0 * npix * macs + 8.0 * npix * k * k, nbytes,
-                     lambda: _lib.load().bts_reduc_lpg_fwd_f32(_ptr(x2d), stride, B, h, w, int(c_in), int(c_first_out),
-                                                               _ptr(w_frag), w_frag.numel(), float(max_depth), k,
-                                                               _ptr(plane4), _ptr(depth_scaled), _ptr(ds_out),
-                                                               _ptr(abs_min), _stream(x2d)))
+        rc = _launch("reduc_lpg_kernel<%d,%d,k%d>" % (c_in, c_first_out, k), "reduc_lpg", 2.0 * npix * macs + 8.0 * npix * k * k, nbytes, run)
     _lib.check(rc, "bts_reduc_lpg_fwd_f32")
     return depth_scaled
 
@@ -671,8 +728,21 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         _lib.load().bts_conv_plan_ksteps_f32(C.byref(d), C.byref(issued), C.byref(dense))
         if dense.value > 0:
             xflops *= issued.value / dense.value
+    tops = torch_ops()
+    if tops is not None:
+        geom = [d.x_pix_stride, d.c_in_ld, d.k_pad, d.B, d.h_in, d.w_in, d.up, d.ksize, d.dil, d.stride, d.pad, d.c_out, d.c_out_pad,
+                d.pre_relu, d.act, d.y_pix_stride, d.y_nchw, d.subpixel, d.y2_pix_stride, d.res_pix_stride, d.n_bundles, d.precision,
+                d.fill_frames]
+        pre_s, pre_b = pre if pre is not None else (None, None)
+        e1_s, e1_b = e1 if e1 is not None else (None, None)
+        e2_s, e2_b = e2 if e2 is not None else (None, None)
+        ws3_t = w_packed._bts_split3 if d.w_split else None
+        run = lambda: _op(lambda: tops.conv_fwd(x2d, w_packed, pre_s, pre_b, e1_s, e1_b, e2_s, e2_b, out, y2_2d, res2d, splitk_ws,
+                                                list(tail_planes) if tail_planes else [], ws3_t, geom))
+    else:
+        run = lambda: _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d))
     with torch.cuda.device(x2d.device):
-        rc = _launch(variant, tag, flops, nbytes, lambda: _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d)), xflops=xflops)
+        rc = _launch(variant, tag, flops, nbytes, run, xflops=xflops)
     _lib.check(rc, "bts_conv_fwd_f32")
     return out
 

@@ -339,3 +339,27 @@ def test_launch_config_is_a_thread_local_scope():
         with pytest.raises(ops.BtsHipError):
             ops.launch_config(**bad)
     assert not hasattr(ops, "set_fill_frames") and not hasattr(ops, "set_conv_precision")
+
+
+def test_torch_operator_library_registers_the_hot_path_ops():
+    """libbts_torch.so (csrc/torch_ops.cpp): TORCH_LIBRARY(bts_hip) over the C ABI -- the operator boundary north_star
+    names.  On a machine without a GPU: the library loads, every operator is registered with the schema the Python side
+    calls, and a CPU tensor is refused loudly (there is no CPU kernel to fall back to)."""
+    import torch
+    from bts_amd import _lib, ops
+    t = _lib.load_torch_ops()
+    want = {"lpg": "bts_hip::lpg(Tensor plane_eq, int upratio) -> (Tensor, Tensor)",
+            "lpg_backward": "bts_hip::lpg_backward(Tensor plane_eq, Tensor grad_depth, int upratio) -> Tensor",
+            "reduction_1x1": None, "reduc_lpg": None, "conv_fwd": None}
+    for name, schema in want.items():
+        op = getattr(t, name)
+        s = str(op.default._schema)
+        assert s.startswith("bts_hip::" + name + "("), s
+        if schema:
+            assert s == schema, s
+    assert "Tensor(a!) y" in str(t.conv_fwd.default._schema) and "int[] geom" in str(t.conv_fwd.default._schema)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        t.lpg(torch.zeros(1, 4, 2, 2), 8)                    # no CPU backend registered
+    assert ops.torch_ops() is t                               # the default binding of the hot-path operators
+    with pytest.raises(ops.BtsHipError):
+        ops.lpg_forward(torch.zeros(1, 4, 2, 2), 8)

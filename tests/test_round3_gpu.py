@@ -286,3 +286,61 @@ def test_split_bf16x3_matches_the_definition():
     assert np.array_equal(planes.numpy().view(np.uint16), want.astype(np.uint16))
     w4 = torch.randn((4, 32, 64), generator=g).cuda()
     assert ops.split_bf16x3(w4).shape == (4, 3, 32, 64)
+
+
+# ------------------------------------------------------------------------------------ torch operator boundary (TORCH_LIBRARY bts_hip)
+def test_torch_ops_validate_and_match_the_ctypes_binding():
+    """torch.ops.bts_hip.* (csrc/torch_ops.cpp): the same launches as the ctypes binding -- bit-identical results -- behind
+    TORCH_CHECK validation (dtype, shape, contiguity, device), a device guard and the CURRENT stream; autograd on
+    bts_hip::lpg equals the oracle's autograd through the reference formulation (bts.py:149-173)."""
+    import subprocess, sys, os
+    from bts_amd import ops
+    from oracle import bts_oracle as O
+    tops = ops.torch_ops()
+    assert tops is not None
+    g = torch.Generator().manual_seed(9)
+    pe = (torch.rand((2, 4, 6, 9), generator=g) + 0.5)
+    # --- lpg: bit-exact module op, abs_min, autograd
+    depth, am = tops.lpg(pe.cuda(), 4)
+    ref, ref_am = O.lpg_forward(pe, 4)
+    assert torch.equal(depth.cpu(), ref) and am.item() == ref_am.item()
+    x = pe.clone().cuda().requires_grad_(True)
+    d2, _ = tops.lpg(x, 8)
+    wgt = torch.rand(d2.shape, generator=g).cuda()
+    (d2 * wgt).sum().backward()
+    xr = pe.clone().requires_grad_(True)
+    (O.lpg_forward(xr, 8)[0] * wgt.cpu()).sum().backward()
+    assert (x.grad.cpu() - xr.grad).abs().max().item() <= 2e-5 * xr.grad.abs().max().item()
+    # on a side stream: the operator launches on the CURRENT stream (the result is ready after that stream syncs)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        big = (torch.rand((8, 4, 44, 152), device="cuda") + 0.5)
+        ds, _ = tops.lpg(big, 8)
+    st.synchronize()
+    assert torch.equal(ds, tops.lpg(big, 8)[0])
+    # --- validation
+    for bad, msg in ((lambda: tops.lpg(pe.cuda().double(), 4), "float32"), (lambda: tops.lpg(pe.cuda()[:, :3], 4), "[B,4,h,w]"),
+                     (lambda: tops.lpg(pe.cuda(), 3), "upratio"),
+                     (lambda: tops.reduction_1x1(torch.zeros((10, 32), device="cuda"), 32, 16, torch.zeros(8, device="cuda"), 80.0, True, True,
+                                                 torch.zeros(9, device="cuda")), "out must hold"),
+                     (lambda: tops.reduction_1x1(torch.zeros((10, 32), device="cuda"), 32, 16, torch.zeros(8, device="cuda"), 80.0, True, True,
+                                                 torch.zeros(10)), "CUDA")):
+        with pytest.raises(RuntimeError) as ei:
+            bad()
+        assert msg in str(ei.value), (msg, str(ei.value)[:200])
+    with pytest.raises(RuntimeError) as ei:                                   # a chain that is not built: the C ABI's code, as text
+        tops.reduction_1x1(torch.zeros((64, 48), device="cuda"), 48, 24, torch.zeros(64, device="cuda"), 80.0, False, True,
+                           torch.zeros(256, device="cuda"))
+    assert "bts_hip::reduction_1x1 failed" in str(ei.value)
+    # --- the whole decoder through both bindings: bit-identical (the ctypes run in a child process: the binding is chosen at import)
+    from parity_util import build_hip_decoder, hip_run
+    got = hip_run(build_hip_decoder("K"), "K", 2, 64, 96, 4321)
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); from bts_amd import ops; assert ops.torch_ops() is None; "
+            "from parity_util import build_hip_decoder, hip_run; torch.save([o.cpu() for o in hip_run(build_hip_decoder('K'), 'K', 2, 64, 96, 4321)], sys.argv[1])"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.pt")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, BTS_BINDING="ctypes"))
+        other = torch.load(out, weights_only=True)
+    assert all(torch.equal(a.cpu(), b) for a, b in zip(got, other)), "torch-op and ctypes bindings differ"
