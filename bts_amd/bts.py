@@ -611,6 +611,7 @@ class BtsModel(nn.Module):
                                             # call per forward afterwards (bts_amd/plan.py, bts_plan_run): the eager
                                             # B=1 loop of bts_test.py:127-147 without ~120 ctypes crossings per frame
         self._plans = PlanCache()
+        self._fp_state = [0, None, -1]      # workspace.tensor_fingerprint: [structure token, cached tensor list, its token]
         self._origin = [self]               # reaches DataParallel replicas through replicate()'s shallow __dict__ copy
         self._enc_plans = {}                # device -> DenseNetHip / ResNetHip (packs + workspaces), shared with replicas
 
@@ -660,6 +661,16 @@ class BtsModel(nn.Module):
                                   % (i, B, c, H, W, dev, tuple(buf.shape), buf.dtype, buf.device))
             res.append(buf)
         return res
+
+    def _apply(self, fn, recurse=True):
+        # .cuda() / .to() / .float(): buffers are REPLACED by new tensor objects -- the cached fingerprint list is stale
+        self._fp_state[0] += 1
+        return super()._apply(fn, recurse)
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        if assign:
+            self._fp_state[0] += 1          # assign=True swaps the parameter objects themselves
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
     def train(self, mode: bool = True):
         # a mode switch is where a training loop hands weights over to evaluation (bts_main.py:193-275 evaluates every

@@ -94,7 +94,10 @@ __global__ __launch_bounds__(64) void eval_finalize_kernel(const double* __restr
             double m[9];
             if (n > 0.0) {
                 const double me = tot[8] / n;
-                m[0] = sqrt(tot[5] / n - me * me) * 100.0;   // silog
+                // silog: the variance of the log error.  In exact arithmetic E[e^2] - E[e]^2 >= 0; in floating point it can
+                // come out a few ulp below zero when all log errors are (almost) equal -- one valid pixel, or a constant
+                // scale error -- and sqrt would turn that into a NaN that then poisons the running accumulator: clamp
+                m[0] = sqrt(fmax(tot[5] / n - me * me, 0.0)) * 100.0;
                 m[1] = tot[6] / n;                            // abs_rel
                 m[2] = tot[9] / n;                            // log10
                 m[3] = sqrt(tot[4] / n);                      // rms
@@ -106,7 +109,11 @@ __global__ __launch_bounds__(64) void eval_finalize_kernel(const double* __restr
             }
             for (int i = 0; i < 9; ++i) per_frame[(long)b * 10 + i] = m[i];
             per_frame[(long)b * 10 + 9] = n;
-            if (accum != nullptr && n > 0.0) {               // samples without valid depth are skipped (bts_main.py:201-203)
+            // A frame whose mask leaves NO pixel (n == 0) is left out of the accumulator.  Deliberate deviation: the reference
+            // skips a sample only on its has_valid_depth flag (bts_main.py:201-203); a sample that passes the flag but has
+            // an empty mask would make its compute_errors (bts_main.py:87-108) average empty arrays -- NaN for all nine
+            // measures, which the running sums never recover from.  per_frame still reports it, with n = 0.
+            if (accum != nullptr && n > 0.0) {
                 for (int i = 0; i < 9; ++i) accum[i] += m[i];
                 accum[9] += 1.0;
             }

@@ -157,15 +157,19 @@ class Plan:
         self.n_patches = len(patches)
         self.n_slots = len(io_tensors)
         self.slots = (C.c_void_p * self.n_slots)()
+        self._lock = threading.Lock()
 
     def run(self, io_tensors: Sequence[torch.Tensor], stream: int):
-        for k, t in enumerate(io_tensors):
-            self.slots[k] = t.data_ptr()
-        rc = _lib.load_real().bts_plan_run(self.ops, self.n_ops, self.patches, self.n_patches, self.slots, self.n_slots,
-                                           C.c_void_p(stream))
-        if rc != 0:
-            bad = next((i for i in range(self.n_ops) if self.ops[i].failed_code != 0), -1)
-            _lib.check(rc, "bts_plan_run (op %d of %d)" % (bad, self.n_ops))
+        # bts_plan_run patches the caller's pointers into the shared `ops` array in place: two threads replaying the same
+        # plan (same model, device, slot and stream) must not interleave between patching and enqueueing
+        with self._lock:
+            for k, t in enumerate(io_tensors):
+                self.slots[k] = t.data_ptr()
+            rc = _lib.load_real().bts_plan_run(self.ops, self.n_ops, self.patches, self.n_patches, self.slots, self.n_slots,
+                                               C.c_void_p(stream))
+            if rc != 0:
+                bad = next((i for i in range(self.n_ops) if self.ops[i].failed_code != 0), -1)
+                _lib.check(rc, "bts_plan_run (op %d of %d)" % (bad, self.n_ops))
 
 
 class PlanCache:

@@ -51,9 +51,16 @@ def make_optimizer(model, learning_rate: float = 1e-4, weight_decay: float = 1e-
     core = model.module if hasattr(model, "module") else model
     if fused is None:
         fused = all(p.is_cuda for p in core.parameters())
-    return torch.optim.AdamW([{'params': core.encoder.parameters(), 'weight_decay': weight_decay},
-                              {'params': core.decoder.parameters(), 'weight_decay': 0}],
-                             lr=learning_rate, eps=adam_eps, fused=fused)
+    opt = torch.optim.AdamW([{'params': core.encoder.parameters(), 'weight_decay': weight_decay},
+                             {'params': core.decoder.parameters(), 'weight_decay': 0}],
+                            lr=learning_rate, eps=adam_eps, fused=fused)
+    # torch's fused optimisers rewrite the parameters WITHOUT bumping Tensor._version, which is what the packed-weight
+    # caches, recorded plans and captured graphs fingerprint: age them after every step, whatever mode the model is in
+    # (a model kept in eval() and stepped by hand would otherwise go on computing with the previous step's packs).
+    # Writers that bypass the optimiser and go through `.data` call bts_amd.workspace.invalidate_packs() themselves.
+    from . import workspace as _workspace
+    opt.register_step_post_hook(lambda optimizer, args, kwargs: _workspace.invalidate_packs())
+    return opt
 
 
 def poly_lr(global_step: int, num_total_steps: int, learning_rate: float, end_learning_rate: float = -1.0) -> float:

@@ -104,7 +104,20 @@ def test_gpu_metrics_hand_sample_and_empty_frames():
     out = E.gpu_compute_errors(pred, gt, "kitti", s["min_depth_eval"], s["max_depth_eval"], accum=acc).cpu().numpy()
     np.testing.assert_allclose(out[0, :9], [s["measures"][n] for n in NAMES], rtol=1e-12)
     assert out[0, 9] == 4 and out[1, 9] == 0 and not out[1, :9].any()
-    assert acc[9].item() == 1.0                    # the frame without valid depth is skipped (bts_main.py:201-203)
+    assert acc[9].item() == 1.0                    # a frame whose mask leaves no pixel is left out of the accumulator
+    # constant scale error (pred = 1.1 gt everywhere) and a single valid pixel: every log error is the same number, the silog
+    # variance E[e^2] - E[e]^2 is zero up to rounding -- it may come out a few ulp NEGATIVE: the result must be ~0, never NaN,
+    # and the accumulator must stay finite
+    g = torch.Generator().manual_seed(3)
+    gt2 = (torch.rand((3, 40, 60), generator=g) * 60 + 2).float()
+    gt2[2] = 0.0
+    gt2[2, 7, 9] = 17.5
+    pred2 = gt2 * 1.1
+    pred2[2] = 21.25
+    acc2 = torch.zeros(10, dtype=torch.float64, device="cuda")
+    out2 = E.gpu_compute_errors(pred2.cuda(), gt2.cuda(), "kitti", 1e-3, 80.0, accum=acc2).cpu().numpy()
+    assert np.isfinite(out2).all() and np.isfinite(acc2.cpu().numpy()).all()
+    assert (np.abs(out2[:, 0]) <= 1e-4).all() and out2[2, 9] == 1            # silog ~ 0 (x100 scale), one valid pixel in frame 2
     from bts_amd._lib import BtsHipError
     with pytest.raises(BtsHipError):
         E.gpu_compute_errors(pred.cpu(), gt.cpu(), "kitti", 1e-3, 80.0)
