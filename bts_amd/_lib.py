@@ -21,7 +21,7 @@ SYMBOLS = (
     "bts_reduc_lpg_fwd_f32", "bts_plan_run", "bts_upconv_combine_f32",
 )
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class ConvDesc(C.Structure):
@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
         ("subpixel", C.c_int), ("y2", C.c_void_p), ("y2_pix_stride", C.c_long),
         ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_long),
         ("res", C.c_void_p), ("res_pix_stride", C.c_long), ("n_bundles", C.c_int), ("precision", C.c_int),
-        ("tail_planes", C.c_void_p * 4), ("n_tail", C.c_int), ("fill_frames", C.c_int), ("w_split", C.c_void_p),
+        ("tail_planes", C.c_void_p * 4), ("n_tail", C.c_int), ("fill_frames", C.c_int), ("w_split", C.c_void_p), ("w_wino", C.c_void_p),
     ]
 
 

@@ -48,6 +48,7 @@ struct ConvKnobs {
     int halo48_w8; long halo48_w8_below;                   // BTS_CONV_HALO48_W8 (0 = never) / _BELOW: 8-wave 48-wide halo tile for declared launches below this many workgroups (default: all)
     long halo_fill;                                        // BTS_CONV_HALO_FILL: declared-launch workgroups from which the halo kernel replaces split-K (200)
     int fill_frames;                                       // BTS_CONV_FILL_FRAMES: default of bts_conv_desc.fill_frames (8)
+    int wino;                                              // BTS_CONV_WINO: 1 = eligible stride-1 3x3 convolutions with Winograd-form weights take the fused F(2x2,3x3) kernel (conv_wino.inc)
     int halo_emu;                                          // BTS_CONV_HALO_EMU: 1 (default) = precision-1 launches with pre-split weights take the bf16x3 halo-tile kernel where eligible, 0 = row-tiled emulation (A/B)
     int halo_dil;                                          // BTS_CONV_HALO_DIL: 1 (default) = the dilation-3 3x3 convolution (ASPP daspp_3) on the dilated halo tile, 2 = also dilation 6 / 12, 0 = none (row-tiled kernel with tap skipping)
     int stagger;                                           // BTS_CONV_STAGGER: 1 (default) = the eight-wave 48-wide halo tile staggers the staging block of waves 4..7 against their SIMD partners 0..3 (A/B)
@@ -63,7 +64,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 150),
                                 (int)env_long("BTS_CONV_1X1_SB", 1), (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), (int)env_long("BTS_CONV_HALO_SB", 1), (int)env_long("BTS_CONV_HALO48_W8", 1), env_long("BTS_CONV_HALO48_W8_BELOW", 1L << 40), env_long("BTS_CONV_HALO_FILL", 200),
                                 (int)(env_long("BTS_CONV_FILL_FRAMES", 8) > 0 ? env_long("BTS_CONV_FILL_FRAMES", 8) : 8),
-                                (int)env_long("BTS_CONV_HALO_EMU", 1), (int)env_long("BTS_CONV_HALO_DIL", 1), (int)env_long("BTS_CONV_STAGGER", 1),
+                                (int)env_long("BTS_CONV_WINO", 0), (int)env_long("BTS_CONV_HALO_EMU", 1), (int)env_long("BTS_CONV_HALO_DIL", 1), (int)env_long("BTS_CONV_STAGGER", 1),
                                 (int)env_long("BTS_CONV_HALO", 1)};
     return k;
 }
@@ -104,6 +105,7 @@ struct ConvArgs {
     int fill_frames;                         // frames assumed to share a launch (bts_conv_desc.fill_frames, resolved)
     int halo_single_a;                       // halo-tile kernel: one channel chunk, one A buffer (set by launch_halo)
     int tapskip;                             // 1: a tile skips the taps that fall outside the map for ALL of its pixels (tile_tapmask)
+    const float* w_wino;                     // Winograd-form weights (bts_conv_desc.w_wino) or null
     const void* w_split;                     // precision 1: weights pre-split into bf16 planes [classes][3][c_out_pad][k_pad] (bts_conv_desc.w_split) or null
     int stagger;                             // halo-tile kernel, eight-wave 48-wide tile: waves 4..7 stage half a step after their SIMD partners 0..3 (set by launch_halo)
 };
@@ -750,6 +752,7 @@ thread_local ConvChoice* g_dry = nullptr;
 
 #include "conv_halo.inc"
 #include "conv_halo_emu.inc"
+#include "conv_wino.inc"
 #include "conv_1x1.inc"
 #include "conv_stem.inc"
 
@@ -920,6 +923,7 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
     if (!d->y_nchw && d->y_pix_stride < d->c_out) return BTS_ERR_INVALID;
     if (d->act < 0 || d->act > 3) return BTS_ERR_INVALID;
     if (d->w_split && ((uintptr_t)d->w_split & 15)) return BTS_ERR_INVALID;
+    if (d->w_wino && ((uintptr_t)d->w_wino & 15)) return BTS_ERR_INVALID;
     // the kernel addresses both operands with 32-bit element offsets
     if ((double)d->B * d->h_in * d->w_in * (double)d->x_pix_stride >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
     if ((double)d->c_out_pad * (double)d->k_pad * (d->subpixel ? 4.0 : 1.0) >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
@@ -971,7 +975,7 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
         if ((double)d->n_bundles * d->c_out_pad * (double)d->k_pad >= 4294967296.0) return BTS_ERR_UNSUPPORTED;
         a.n_classes = d->n_bundles; a.bundled = 1;
     } else if (d->n_bundles < 0) return BTS_ERR_INVALID;
-    a.ksplit = 1; a.its_per_split = 0; a.ws_ld = 0; a.tapskip = 0; a.halo_single_a = 0; a.stagger = 0; a.w_split = d->w_split;
+    a.ksplit = 1; a.its_per_split = 0; a.ws_ld = 0; a.tapskip = 0; a.halo_single_a = 0; a.stagger = 0; a.w_split = d->w_split; a.w_wino = d->w_wino;
     a.ws = d->splitk_ws;
     const long wsf = d->splitk_ws ? d->splitk_ws_floats : 0;
     if (d->splitk_ws && (((uintptr_t)d->splitk_ws & 15) || d->splitk_ws_floats < 0)) return BTS_ERR_INVALID;
@@ -1041,6 +1045,15 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
             if (wide == 256) return launch_conv1x1<256>(a, s);
             return launch_conv1x1<128>(a, s);
         }
+    }
+    // fused Winograd F(2x2,3x3) (conv_wino.inc): same geometry-only gating as the halo kernel (never instead of split-K
+    // unless the declared launch fills the chip)
+    if (knobs().wino && (bn == 128 || bn == 64 || bn == 48) && wino_eligible(a, nchw)) {
+        ConvArgs probe = a;
+        probe.n_ntiles = (a.c_out + bn - 1) / bn;
+        const long wgs = (long)a.fill_frames * ((a.H + 7) / 8) * ((a.W + 15) / 16) * ((a.c_out + 127) / 128);
+        if (split_factor(probe, wsf) <= 1 || wgs >= knobs().halo_fill)
+            return bn == 128 ? launch_wino<128>(a, s) : launch_wino<64>(a, s);
     }
     // stride-1 3x3 (and sub-pixel 2x2) convolutions on maps that tile well: the halo-tile kernel (conv_halo.inc).  The
     // choice depends on per-frame geometry and the DECLARED frames per launch only (never on B), like the split-K

@@ -577,6 +577,26 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
     return (planes >> 16).to(torch.int16).contiguous()
 
 
+_WINO = os.environ.get("BTS_CONV_WINO", "0").strip() not in ("", "0")
+
+
+def pack_wino_weight(w_packed: torch.Tensor, c_in_ld: int) -> torch.Tensor:
+    """Winograd F(2x2,3x3) form of a packed 3x3 weight ([c_out_pad, 9 * c_in_ld], tap-major K as pack_conv_weight lays
+    it out; c_in_ld a multiple of 32): U = G g G^T per (output, input) channel, computed in fp64 and rounded once, in the
+    B-fragment order conv_wino_kernel loads: float index (((((xi * nchunks + chunk) * n_ct + ct) * 4 + g) * 64 + lh * 32 + li) * 4 + q
+    = U[xi][n = 32 ct + li][k = 32 chunk + 8 g + 4 lh + q]."""
+    _need(w_packed, "pack_wino_weight")
+    cop = w_packed.shape[0]
+    if c_in_ld % 32 or cop % 32 or w_packed.shape[1] != 9 * c_in_ld:
+        raise BtsHipError("pack_wino_weight: needs a 3x3 weight packed with c_in_ld % 32 == 0")
+    g = w_packed.view(cop, 3, 3, c_in_ld).permute(0, 3, 1, 2).double()                   # [n, k, 3, 3]
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w_packed.device)
+    U = torch.einsum("ia,nkab,jb->nkij", G, g, G).float().reshape(cop, c_in_ld, 16)       # [n, k, xi = 4 i + j]
+    n_ct, nchunks = cop // 32, c_in_ld // 32
+    U = U.view(n_ct, 32, nchunks, 4, 2, 4, 16)                                            # (ct, li, chunk, g, lh, q, xi)
+    return U.permute(6, 2, 0, 3, 4, 1, 5).contiguous().view(-1)                            # (xi, chunk, ct, g, lh, li, q)
+
+
 def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torch.Tensor, c_out: int,
                  ksize: int, dil: int = 1, up: int = 1, c_in_ld: Optional[int] = None,
                  pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_relu: bool = False,
@@ -644,6 +664,14 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     keep = []
     d.n_bundles = n_bundles if n_bundles > 1 else 0
     d.fill_frames, d.precision = current_launch_config()
+    if (_WINO and d.precision == 0 and ksize == 3 and stride == 1 and dil == 1 and pad == 1 and up == 1 and not subpixel
+            and n_bundles <= 1 and not n_tail and c_in_ld % 32 == 0 and y_nchw is None):
+        uw = getattr(w_packed, "_bts_wino", None)
+        if uw is None:
+            uw = pack_wino_weight(w_packed, c_in_ld)
+            w_packed._bts_wino = uw
+        keep.append(uw)
+        d.w_wino = uw.data_ptr()
     if d.precision == 1 and n_bundles <= 1 and not n_tail:
         # weights pre-split into bf16 planes for the emulated mode's halo-tile kernel (LDS-DMA of plain bytes); made once
         # per packed weight tensor and kept on it
@@ -711,7 +739,9 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         bm, bn, kind = C.c_int(0), C.c_int(0), C.c_int(0)
         _lib.load().bts_conv_plan_f32(C.byref(d), C.byref(bm), C.byref(bn), C.byref(kind))
         lay = "nchw" if y_nchw is not None else "nhwc"
-        if (kind.value & 15) == 5:
+        if (kind.value & 15) == 6:
+            variant = "conv_wino_kernel<%d>" % bn.value
+        elif (kind.value & 15) == 5:
             variant = "conv_halo_emu_kernel<%d,k%d>" % (bn.value, 2 if subpixel else 3)
         elif (kind.value & 15) == 4:
             variant = "conv_stem_kernel<%d>" % bn.value
@@ -728,7 +758,7 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         _lib.load().bts_conv_plan_ksteps_f32(C.byref(d), C.byref(issued), C.byref(dense))
         if dense.value > 0:
             xflops *= issued.value / dense.value
-    tops = torch_ops()
+    tops = torch_ops() if not d.w_wino else None      # (the Winograd experiment binds through ctypes only)
     if tops is not None:
         geom = [d.x_pix_stride, d.c_in_ld, d.k_pad, d.B, d.h_in, d.w_in, d.up, d.ksize, d.dil, d.stride, d.pad, d.c_out, d.c_out_pad,
                 d.pre_relu, d.act, d.y_pix_stride, d.y_nchw, d.subpixel, d.y2_pix_stride, d.res_pix_stride, d.n_bundles, d.precision,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 12
+#define BTS_HIP_ABI_VERSION 13
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -198,6 +198,11 @@ typedef struct bts_conv_desc {
                                 (the kernels' own truncation split; bts_amd/ops.py:split_bf16x3).  With it the halo-tile
                                 kernel of the emulated mode streams weight tiles global -> LDS by LDS-DMA; NULL = the
                                 row-tiled kernel splits `w` on the fly.  16-byte aligned.                                  */
+    const float* w_wino;       /* optional, precision = 0, stride-1 3x3 / padding 1 / dilation 1 only: the weights in Winograd
+                                F(2x2,3x3) form U = G g G^T, in MFMA B-fragment order [16 xi][c_in_ld/32][c_out_pad/32][4][64][4]
+                                (bts_amd/ops.py:pack_wino_weight).  With it (and $BTS_CONV_WINO) eligible layers run the fused
+                                Winograd kernel (csrc/conv_wino.inc): 2.25x fewer MFMA products, results equal to the direct
+                                kernels' up to fp32 rounding of the transforms.  NULL = direct kernels.  16-byte aligned.   */
 } bts_conv_desc;
 
 int bts_conv_fwd_f32(const bts_conv_desc* desc, bts_stream_t stream);

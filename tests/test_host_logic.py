@@ -29,9 +29,9 @@ def test_cabi_exports_every_declared_symbol():
 
 def test_conv_desc_layout_matches_header():
     from bts_amd._lib import ConvDesc
-    assert ctypes.sizeof(ConvDesc) == 264
+    assert ctypes.sizeof(ConvDesc) == 272
     assert ConvDesc.w.offset == 56 and ConvDesc.y.offset == 136 and ConvDesc.y_nchw.offset == 152
-    assert ConvDesc.tail_planes.offset == 216 and ConvDesc.n_tail.offset == 248 and ConvDesc.w_split.offset == 256
+    assert ConvDesc.tail_planes.offset == 216 and ConvDesc.n_tail.offset == 248 and ConvDesc.w_split.offset == 256 and ConvDesc.w_wino.offset == 264
 
 
 @pytest.mark.parametrize("enc", ["densenet161_bts", "resnext101_bts", "densenet121_bts", "resnet50_bts"])

@@ -344,3 +344,48 @@ def test_torch_ops_validate_and_match_the_ctypes_binding():
         subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, BTS_BINDING="ctypes"))
         other = torch.load(out, weights_only=True)
     assert all(torch.equal(a.cpu(), b) for a, b in zip(got, other)), "torch-op and ctypes bindings differ"
+
+
+# ------------------------------------------------------------------------------- fused Winograd F(2x2,3x3) kernel (conv_wino.inc)
+def _wino_case(cin, cout, shape, pre):
+    import torch.nn.functional as F
+    from bts_amd import ops
+    B, h, w = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout + h)
+    x = torch.randn((B, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(cin * 9.0)
+    ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    xin = torch.relu(x.double() * ps.double().view(1, -1, 1, 1) + pb.double().view(1, -1, 1, 1)) if pre else x.double()
+    ref = F.elu(F.conv2d(xin, wt.double(), padding=1))
+    x2d = x.permute(0, 2, 3, 1).reshape(B * h * w, cin).contiguous().cuda()
+    wp = ops.pack_conv_weight(wt.cuda())[0]
+    ybuf = torch.zeros((B * h * w, cout + 32), device="cuda")
+    y = ybuf[:, 16:16 + cout]
+    tr = ops.KernelTrace()
+    ops.set_trace(tr)
+    try:
+        with ops.launch_config(fill_frames=16):
+            ops.conv_forward(x2d, B, h, w, wp, cout, 3, act=ops.ACT_ELU, y2d=y, pre=(ps.cuda(), pb.cuda()) if pre else None, pre_relu=pre)
+    finally:
+        ops.set_trace(None)
+    got = y.reshape(B, h, w, cout).permute(0, 3, 1, 2).cpu().double()
+    assert float(ybuf[:, :16].abs().max()) == 0.0 and float(ybuf[:, 16 + cout:].abs().max()) == 0.0
+    return sorted(tr.summary())[0], (got - ref).abs().max().item() / ref.abs().max().item(), y.cpu()
+
+
+@fp32_only
+@pytest.mark.parametrize("cin,cout,shape,pre", [(64, 128, (2, 44, 152), True), (448, 256, (1, 44, 152), False), (192, 48, (2, 88, 304), True),
+                                                (128, 64, (1, 45, 150), True), (32, 128, (3, 15, 47), True)])
+def test_winograd_kernel_vs_fp64_and_direct(cin, cout, shape, pre):
+    """conv_wino_kernel (BTS_CONV_WINO=1): fused Winograd F(2x2,3x3) for stride-1 3x3 convolutions against torch in fp64,
+    next to the direct kernel's own error on the same case; odd map sizes (ragged 8x16 workgroup tiles, odd last row /
+    column of a 2x2 block), prologue + zero padding, ELU epilogue into a strided channel slice."""
+    import os, subprocess, sys
+    if os.environ.get("BTS_CONV_WINO", "0") in ("", "0"):
+        kern, err_direct, _ = _wino_case(cin, cout, shape, pre)
+        assert not kern.startswith("conv_wino")
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_round3_gpu as R; "
+                "k, e, _ = R._wino_case(%d, %d, %r, %r); print('WINO', k, e); assert k == 'conv_wino_kernel<%d>', k; assert e <= max(1e-5, 4 * %r), e"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), cin, cout, shape, pre,
+                   128 if cout >= 128 else 64, err_direct))
+        subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BTS_CONV_WINO="1"))
