@@ -48,7 +48,7 @@ struct ConvKnobs {
     int halo48_w8; long halo48_w8_below;                   // BTS_CONV_HALO48_W8 (0 = never) / _BELOW: 8-wave 48-wide halo tile for declared launches below this many workgroups (default: all)
     long halo_fill;                                        // BTS_CONV_HALO_FILL: declared-launch workgroups from which the halo kernel replaces split-K (200)
     int fill_frames;                                       // BTS_CONV_FILL_FRAMES: default of bts_conv_desc.fill_frames (8)
-    int wino;                                              // BTS_CONV_WINO: 1 = eligible stride-1 3x3 convolutions with Winograd-form weights take the fused F(2x2,3x3) kernel (conv_wino.inc)
+    int wino;                                              // BTS_CONV_WINO: 1 (default) = eligible stride-1 3x3 convolutions whose caller supplies Winograd-form weights take the fused F(2x2,3x3) kernel (conv_wino.inc); 0 = direct kernels (A/B)
     int halo_emu;                                          // BTS_CONV_HALO_EMU: 1 (default) = precision-1 launches with pre-split weights take the bf16x3 halo-tile kernel where eligible, 0 = row-tiled emulation (A/B)
     int halo_dil;                                          // BTS_CONV_HALO_DIL: 1 (default) = the dilation-3 3x3 convolution (ASPP daspp_3) on the dilated halo tile, 2 = also dilation 6 / 12, 0 = none (row-tiled kernel with tap skipping)
     int stagger;                                           // BTS_CONV_STAGGER: 1 (default) = the eight-wave 48-wide halo tile staggers the staging block of waves 4..7 against their SIMD partners 0..3 (A/B)
@@ -64,7 +64,7 @@ const ConvKnobs& knobs() {
                                 (int)env_long("BTS_CONV_1X1", 1), env_long("BTS_CONV_1X1_MIN_TILES", 150),
                                 (int)env_long("BTS_CONV_1X1_SB", 1), (int)env_long("BTS_CONV_1X1_ROWS", 0), (int)env_long("BTS_CONV_STEM", 1), (int)env_long("BTS_CONV_TAPSKIP", 1), (int)env_long("BTS_CONV_HALO_SB", 1), (int)env_long("BTS_CONV_HALO48_W8", 1), env_long("BTS_CONV_HALO48_W8_BELOW", 1L << 40), env_long("BTS_CONV_HALO_FILL", 200),
                                 (int)(env_long("BTS_CONV_FILL_FRAMES", 8) > 0 ? env_long("BTS_CONV_FILL_FRAMES", 8) : 8),
-                                (int)env_long("BTS_CONV_WINO", 0), (int)env_long("BTS_CONV_HALO_EMU", 1), (int)env_long("BTS_CONV_HALO_DIL", 1), (int)env_long("BTS_CONV_STAGGER", 1),
+                                (int)env_long("BTS_CONV_WINO", 1), (int)env_long("BTS_CONV_HALO_EMU", 1), (int)env_long("BTS_CONV_HALO_DIL", 1), (int)env_long("BTS_CONV_STAGGER", 1),
                                 (int)env_long("BTS_CONV_HALO", 1)};
     return k;
 }
@@ -1048,7 +1048,7 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
     }
     // fused Winograd F(2x2,3x3) (conv_wino.inc): same geometry-only gating as the halo kernel (never instead of split-K
     // unless the declared launch fills the chip)
-    if (knobs().wino && (bn == 128 || bn == 64 || bn == 48) && wino_eligible(a, nchw)) {
+    if (knobs().wino && (bn == 128 || bn == 64 || bn == 48) && a.c_out_pad % (bn == 128 ? 128 : 64) == 0 && wino_eligible(a, nchw)) {
         ConvArgs probe = a;
         probe.n_ntiles = (a.c_out + bn - 1) / bn;
         const long wgs = (long)a.fill_frames * ((a.H + 7) / 8) * ((a.W + 15) / 16) * ((a.c_out + 127) / 128);

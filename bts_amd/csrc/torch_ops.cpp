@@ -143,7 +143,7 @@ constexpr int kGeomLen = 23;
 
 void conv_fwd(const Tensor& x, const Tensor& w, OptTensor pre_scale, OptTensor pre_shift, OptTensor e1_scale, OptTensor e1_shift,
               OptTensor e2_scale, OptTensor e2_shift, Tensor y, OptTensor y2, OptTensor res, OptTensor splitk_ws,
-              std::vector<Tensor> tail_planes, OptTensor w_split, std::vector<int64_t> geom) {
+              std::vector<Tensor> tail_planes, OptTensor w_split, OptTensor w_wino, std::vector<int64_t> geom) {
     const char* op = "bts_hip::conv_fwd";
     TORCH_CHECK((int)geom.size() == kGeomLen, op, ": geom must hold ", kGeomLen, " integers, got ", geom.size());
     need_f32_cuda(x, op, "x");
@@ -223,6 +223,13 @@ void conv_fwd(const Tensor& x, const Tensor& w, OptTensor pre_scale, OptTensor p
         same_device(x, *w_split, op, "w_split");
         d.w_split = w_split->data_ptr();
     }
+    if (w_wino.has_value() && w_wino->defined()) {
+        need_f32_cuda(*w_wino, op, "w_wino");
+        same_device(x, *w_wino, op, "w_wino");
+        TORCH_CHECK(w_wino->is_contiguous() && w_wino->numel() == (int64_t)16 * d.c_out_pad * d.c_in_ld, op,
+                    ": w_wino must be the contiguous Winograd form of w, 16 * c_out_pad * c_in_ld floats (ops.pack_wino_weight)");
+        d.w_wino = w_wino->data_ptr<float>();
+    }
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     check_rc(bts_conv_fwd_f32(&d, current_stream()), op);
 }
@@ -237,7 +244,7 @@ TORCH_LIBRARY(bts_hip, m) {
           "Tensor(a!) depth_scaled, Tensor(b!)? ds_out, Tensor(c!)? abs_min, Tensor(d!)? plane4) -> ()");
     m.def("conv_fwd(Tensor x, Tensor w, Tensor? pre_scale, Tensor? pre_shift, Tensor? e1_scale, Tensor? e1_shift, Tensor? e2_scale, "
           "Tensor? e2_shift, Tensor(a!) y, Tensor(b!)? y2, Tensor? res, Tensor(c!)? splitk_ws, Tensor[] tail_planes, Tensor? w_split, "
-          "int[] geom) -> ()");
+          "Tensor? w_wino, int[] geom) -> ()");
 }
 
 TORCH_LIBRARY_IMPL(bts_hip, CUDA, m) {

@@ -577,7 +577,7 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
     return (planes >> 16).to(torch.int16).contiguous()
 
 
-_WINO = os.environ.get("BTS_CONV_WINO", "0").strip() not in ("", "0")
+_WINO = os.environ.get("BTS_CONV_WINO", "1").strip() not in ("", "0")      # fused Winograd F(2x2,3x3) for eligible 3x3 layers (0: direct kernels, A/B)
 
 
 def pack_wino_weight(w_packed: torch.Tensor, c_in_ld: int) -> torch.Tensor:
@@ -758,7 +758,7 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         _lib.load().bts_conv_plan_ksteps_f32(C.byref(d), C.byref(issued), C.byref(dense))
         if dense.value > 0:
             xflops *= issued.value / dense.value
-    tops = torch_ops() if not d.w_wino else None      # (the Winograd experiment binds through ctypes only)
+    tops = torch_ops()
     if tops is not None:
         geom = [d.x_pix_stride, d.c_in_ld, d.k_pad, d.B, d.h_in, d.w_in, d.up, d.ksize, d.dil, d.stride, d.pad, d.c_out, d.c_out_pad,
                 d.pre_relu, d.act, d.y_pix_stride, d.y_nchw, d.subpixel, d.y2_pix_stride, d.res_pix_stride, d.n_bundles, d.precision,
@@ -767,8 +767,9 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         e1_s, e1_b = e1 if e1 is not None else (None, None)
         e2_s, e2_b = e2 if e2 is not None else (None, None)
         ws3_t = w_packed._bts_split3 if d.w_split else None
+        uw_t = w_packed._bts_wino if d.w_wino else None
         run = lambda: _op(lambda: tops.conv_fwd(x2d, w_packed, pre_s, pre_b, e1_s, e1_b, e2_s, e2_b, out, y2_2d, res2d, splitk_ws,
-                                                list(tail_planes) if tail_planes else [], ws3_t, geom))
+                                                list(tail_planes) if tail_planes else [], ws3_t, uw_t, geom))
     else:
         run = lambda: _lib.load().bts_conv_fwd_f32(C.byref(d), _stream(x2d))
     with torch.cuda.device(x2d.device):

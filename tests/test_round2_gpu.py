@@ -794,7 +794,7 @@ def test_tap_skipping_leaves_every_bit_unchanged(dil, shape):
 @fp32_only
 def test_fill_frames_16_block3_on_wide_and_halo_kernels_frame_independent_cpu_parity():
     """fill_frames 16 (what a model left at its default declares from B = 12 on, bench.py's B=16 included): DenseNet block 3 then runs on the wide 1x1 tile and the eight-wave 48-wide
-    halo tile instead of the row-tiled / split-K kernels (checked through the launch trace).  At full size (B=16,
+    halo tile -- since round 3 the fused Winograd kernel -- instead of the row-tiled / split-K kernels (checked through the launch trace).  At full size (B=16,
     352x1216, four sub-batch streams): frames 0 and 15 of the batch bit-equal to the same frames run alone under the same
     declaration, the result within fp32 summation noise of the default declaration, and frame 0 vs the torch-CPU encoder
     + CPU oracle decoder."""
@@ -820,7 +820,7 @@ def test_fill_frames_16_block3_on_wide_and_halo_kernels_frame_independent_cpu_pa
                 if r[1] in b3:
                     b3[r[1]].add(r[0])
             assert b3["enc_b3_1x1"] == {"conv1x1_kernel<192,2>", "conv1x1_kernel<192,4>"}, b3
-            assert b3["enc_b3_3x3"] == {"conv_halo_kernel<48,k3,nhwc,w8>"}, b3
+            assert b3["enc_b3_3x3"] == {"conv_wino_kernel<64>"}, b3      # (BTS_CONV_WINO=0: conv_halo_kernel<48,k3,nhwc,w8>)
             one15 = m(img[15:16].cuda(), foc[15:16].cuda())
             for a, b, c in zip(one0, one15, full):
                 assert torch.equal(a[0], c[0]) and torch.equal(b[0], c[15]), "a frame depends on its batch under fill_frames=16"

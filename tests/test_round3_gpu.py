@@ -380,12 +380,32 @@ def test_winograd_kernel_vs_fp64_and_direct(cin, cout, shape, pre):
     """conv_wino_kernel (BTS_CONV_WINO=1): fused Winograd F(2x2,3x3) for stride-1 3x3 convolutions against torch in fp64,
     next to the direct kernel's own error on the same case; odd map sizes (ragged 8x16 workgroup tiles, odd last row /
     column of a 2x2 block), prologue + zero padding, ELU epilogue into a strided channel slice."""
-    import os, subprocess, sys
-    if os.environ.get("BTS_CONV_WINO", "0") in ("", "0"):
-        kern, err_direct, _ = _wino_case(cin, cout, shape, pre)
-        assert not kern.startswith("conv_wino")
-        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_round3_gpu as R; "
-                "k, e, _ = R._wino_case(%d, %d, %r, %r); print('WINO', k, e); assert k == 'conv_wino_kernel<%d>', k; assert e <= max(1e-5, 4 * %r), e"
-                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), cin, cout, shape, pre,
-                   128 if cout >= 128 else 64, err_direct))
-        subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, BTS_CONV_WINO="1"))
+    import os, subprocess, sys, tempfile
+    if os.environ.get("BTS_CONV_WINO", "1") in ("", "0"):
+        pytest.skip("direct kernels forced by BTS_CONV_WINO=0")
+    kern, err_wino, y = _wino_case(cin, cout, shape, pre)
+    assert kern == "conv_wino_kernel<%d>" % (128 if cout >= 128 else 64), kern
+    # the direct kernel on the same case, in a child process (the knob is read once per process)
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_round3_gpu as R; "
+            "k, e, y = R._wino_case(%d, %d, %r, %r); assert not k.startswith('conv_wino'), k; torch.save((e, y), sys.argv[1])"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), cin, cout, shape, pre))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "y.pt")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, BTS_CONV_WINO="0"))
+        err_direct, y_direct = torch.load(out, weights_only=True)
+    print((cin, cout, shape), "max error / max|ref|: winograd %.3g, direct %.3g" % (err_wino, err_direct))
+    assert err_wino <= max(1e-5, 4 * err_direct), (err_wino, err_direct)
+    assert (y - y_direct).abs().max().item() / y_direct.abs().max().item() <= 2e-5
+    B, h, w = shape
+    if B > 1:                                   # frames are independent: the last frame alone gives the same bits
+        from bts_amd import ops
+        g = torch.Generator().manual_seed(cin * 7 + cout + h)
+        x = torch.randn((B, cin, h, w), generator=g)
+        wt = torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(cin * 9.0)
+        ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+        x1 = x[B - 1:].permute(0, 2, 3, 1).reshape(h * w, cin).contiguous().cuda()
+        wp = ops.pack_conv_weight(wt.cuda())[0]
+        y1 = torch.zeros((h * w, cout), device="cuda")
+        with ops.launch_config(fill_frames=16):
+            ops.conv_forward(x1, 1, h, w, wp, cout, 3, act=ops.ACT_ELU, y2d=y1, pre=(ps.cuda(), pb.cuda()) if pre else None, pre_relu=pre)
+        assert torch.equal(y1.cpu(), y[(B - 1) * h * w:])
