@@ -106,6 +106,9 @@ def trace_to_rocprof_name(kernel):
     m = re.match(r"conv_stem_kernel<(\d+)>", kernel)
     if m:
         return r"conv_stem_kernel<%s>" % m.group(1)
+    m = re.match(r"conv_(wino|halo_emu)_kernel<([\d,k]+)>", kernel)
+    if m:
+        return r"conv_%s_kernel<%s>" % (m.group(1), m.group(2).replace("k", ""))
     m = re.match(r"conv1x1_kernel<(\d+),(\d+)>", kernel)
     if m:
         return r"conv1x1_kernel<%s,%s(,true|,false)?>" % (m.group(1), m.group(2))      # 3rd parameter: single weight buffer

@@ -988,6 +988,9 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
     const int prec_env = knobs().precision;
     const int prec = prec_env >= 0 ? prec_env : d->precision;
     if (prec != 0 && prec != 1) return BTS_ERR_INVALID;
+    // fused Winograd F(2x2,3x3) (conv_wino.inc), planar-tail layers included (conv3 / conv2: NHWC output)
+    if (a.n_tail > 0 && prec == 0 && knobs().wino && (bn == 128 || bn == 64) && a.c_out_pad % (bn == 128 ? 128 : 64) == 0 && wino_eligible(a, nchw))
+        return bn == 128 ? launch_wino<128, true>(a, s) : launch_wino<64, true>(a, s);
     if (a.n_tail > 0) {   // planar tail operand: always the halo-tile kernel (fp32-input MFMA whatever `precision` says)
         if (bn == 128) return launch_halo<128, 4, 2, 32, 3, true>(a, nchw, s);
         if (bn == 32) return launch_halo<32, 4, 1, 32, 3, true>(a, nchw, s);

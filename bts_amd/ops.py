@@ -580,21 +580,26 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
 _WINO = os.environ.get("BTS_CONV_WINO", "1").strip() not in ("", "0")      # fused Winograd F(2x2,3x3) for eligible 3x3 layers (0: direct kernels, A/B)
 
 
-def pack_wino_weight(w_packed: torch.Tensor, c_in_ld: int) -> torch.Tensor:
+def pack_wino_weight(w_packed: torch.Tensor, c_in_ld: int, n_tail: int = 0) -> torch.Tensor:
     """Winograd F(2x2,3x3) form of a packed 3x3 weight ([c_out_pad, 9 * c_in_ld], tap-major K as pack_conv_weight lays
-    it out; c_in_ld a multiple of 32): U = G g G^T per (output, input) channel, computed in fp64 and rounded once, in the
-    B-fragment order conv_wino_kernel loads: float index (((((xi * nchunks + chunk) * n_ct + ct) * 4 + g) * 64 + lh * 32 + li) * 4 + q
-    = U[xi][n = 32 ct + li][k = 32 chunk + 8 g + 4 lh + q]."""
+    it out): U = G g G^T per (output, input) channel, computed in fp64 and rounded once, in the B-fragment order
+    conv_wino_kernel loads: float index (((((xi * nchunks + chunk) * n_ct + ct) * 4 + g) * 64 + lh * 32 + li) * 4 + q
+    = U[xi][n = 32 ct + li][k = 32 chunk + 8 g + 4 lh + q].  ``n_tail`` > 0: the last 4 of the c_in_ld input channels are
+    the planar tail operand (bts_conv_desc.tail_planes): U covers the c_in_ld - 4 buffer channels only (whole chunks) --
+    the kernel adds the tail's products directly from the packed fp32 weights."""
     _need(w_packed, "pack_wino_weight")
     cop = w_packed.shape[0]
-    if c_in_ld % 32 or cop % 32 or w_packed.shape[1] != 9 * c_in_ld:
-        raise BtsHipError("pack_wino_weight: needs a 3x3 weight packed with c_in_ld % 32 == 0")
-    g = w_packed.view(cop, 3, 3, c_in_ld).permute(0, 3, 1, 2).double()                   # [n, k, 3, 3]
+    c_main = c_in_ld - (4 if n_tail else 0)
+    if c_main <= 0 or c_main % 32 or cop % 32 or w_packed.shape[1] != round_up(9 * c_in_ld, 32):
+        raise BtsHipError("pack_wino_weight: needs a 3x3 weight whose buffer channels are whole 32-channel chunks")
+    g = w_packed[:, :9 * c_in_ld].reshape(cop, 3, 3, c_in_ld).permute(0, 3, 1, 2).double()     # [n, k, 3, 3]
+    g = g[:, :c_main]
+    c_tot = g.shape[1]
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w_packed.device)
-    U = torch.einsum("ia,nkab,jb->nkij", G, g, G).float().reshape(cop, c_in_ld, 16)       # [n, k, xi = 4 i + j]
-    n_ct, nchunks = cop // 32, c_in_ld // 32
-    U = U.view(n_ct, 32, nchunks, 4, 2, 4, 16)                                            # (ct, li, chunk, g, lh, q, xi)
-    return U.permute(6, 2, 0, 3, 4, 1, 5).contiguous().view(-1)                            # (xi, chunk, ct, g, lh, li, q)
+    U = torch.einsum("ia,nkab,jb->nkij", G, g, G).float().reshape(cop, c_tot, 16)               # [n, k, xi = 4 i + j]
+    n_ct, nchunks = cop // 32, c_tot // 32
+    U = U.view(n_ct, 32, nchunks, 4, 2, 4, 16)                                                  # (ct, li, chunk, g, lh, q, xi)
+    return U.permute(6, 2, 0, 3, 4, 1, 5).contiguous().view(-1)                                  # (xi, chunk, ct, g, lh, li, q)
 
 
 def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torch.Tensor, c_out: int,
@@ -665,10 +670,10 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     d.n_bundles = n_bundles if n_bundles > 1 else 0
     d.fill_frames, d.precision = current_launch_config()
     if (_WINO and d.precision == 0 and ksize == 3 and stride == 1 and dil == 1 and pad == 1 and up == 1 and not subpixel
-            and n_bundles <= 1 and not n_tail and c_in_ld % 32 == 0 and y_nchw is None):
+            and n_bundles <= 1 and (c_in_ld - (4 if n_tail else 0)) % 32 == 0 and c_in_ld > 4 and y_nchw is None):
         uw = getattr(w_packed, "_bts_wino", None)
         if uw is None:
-            uw = pack_wino_weight(w_packed, c_in_ld)
+            uw = pack_wino_weight(w_packed, c_in_ld, n_tail)
             w_packed._bts_wino = uw
         keep.append(uw)
         d.w_wino = uw.data_ptr()
@@ -753,6 +758,12 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         else:
             variant = "conv_fwd_kernel<%d,%d,%s%s>" % (bm.value, bn.value, lay, ",splitk" if kind.value & 16 else "")
     xflops = 2.0 * npix_out * c_out * (c_in_ld if n_bundles > 1 else cin) * taps
+    if _trace is not None and variant.startswith("conv_wino_kernel"):
+        # MFMA products the Winograd kernel ISSUES: 16 transform positions x 32 tiles x BN channels x c_in per workgroup
+        # (4 instead of 9 per output and input channel, plus the ragged 8x16-pixel tiles and the channels padded to BN)
+        bn_w = bn.value
+        nwg = B * ((H + 7) // 8) * ((W + 15) // 16) * ((c_out + bn_w - 1) // bn_w)
+        xflops = 2.0 * nwg * 16 * 32 * bn_w * c_in_ld
     if _trace is not None:                                 # tap skipping (dilated ASPP branches): FLOPs really issued
         issued, dense = C.c_long(0), C.c_long(0)
         _lib.load().bts_conv_plan_ksteps_f32(C.byref(d), C.byref(issued), C.byref(dense))
