@@ -1051,12 +1051,13 @@ int conv_dispatch(const bts_conv_desc* d, bts_stream_t stream) {
     }
     // fused Winograd F(2x2,3x3) (conv_wino.inc): same geometry-only gating as the halo kernel (never instead of split-K
     // unless the declared launch fills the chip)
-    if (knobs().wino && (bn == 128 || bn == 64 || bn == 48) && a.c_out_pad % (bn == 128 ? 128 : 64) == 0 && wino_eligible(a, nchw)) {
+    if (knobs().wino && ((bn == 128 && a.c_out_pad % 128 == 0) || (bn == 64 && a.c_out_pad % 64 == 0) || (bn == 48 && a.c_out % 48 == 0)) &&
+        wino_eligible(a, nchw)) {
         ConvArgs probe = a;
         probe.n_ntiles = (a.c_out + bn - 1) / bn;
         const long wgs = (long)a.fill_frames * ((a.H + 7) / 8) * ((a.W + 15) / 16) * ((a.c_out + 127) / 128);
         if (split_factor(probe, wsf) <= 1 || wgs >= knobs().halo_fill)
-            return bn == 128 ? launch_wino<128>(a, s) : launch_wino<64>(a, s);
+            return bn == 128 ? launch_wino<128>(a, s) : (bn == 64 ? launch_wino<64>(a, s) : launch_wino<48>(a, s));
     }
     // stride-1 3x3 (and sub-pixel 2x2) convolutions on maps that tile well: the halo-tile kernel (conv_halo.inc).  The
     // choice depends on per-frame geometry and the DECLARED frames per launch only (never on B), like the split-K

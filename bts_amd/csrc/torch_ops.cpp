@@ -226,7 +226,8 @@ void conv_fwd(const Tensor& x, const Tensor& w, OptTensor pre_scale, OptTensor p
     if (w_wino.has_value() && w_wino->defined()) {
         need_f32_cuda(*w_wino, op, "w_wino");
         same_device(x, *w_wino, op, "w_wino");
-        TORCH_CHECK(w_wino->is_contiguous() && w_wino->numel() == (int64_t)16 * d.c_out_pad * (d.n_tail > 0 ? d.c_in_ld - 4 : d.c_in_ld), op,
+        const int64_t cm = d.n_tail > 0 ? d.c_in_ld - 4 : d.c_in_ld;
+        TORCH_CHECK(w_wino->is_contiguous() && (w_wino->numel() == (int64_t)16 * d.c_out_pad * cm || w_wino->numel() == (int64_t)16 * d.c_out * cm), op,
                     ": w_wino must be the contiguous Winograd form of w, 16 * c_out_pad * (buffer channels) floats (ops.pack_wino_weight)");
         d.w_wino = w_wino->data_ptr<float>();
     }

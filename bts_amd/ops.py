@@ -580,13 +580,16 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
 _WINO = os.environ.get("BTS_CONV_WINO", "1").strip() not in ("", "0")      # fused Winograd F(2x2,3x3) for eligible 3x3 layers (0: direct kernels, A/B)
 
 
-def pack_wino_weight(w_packed: torch.Tensor, c_in_ld: int, n_tail: int = 0) -> torch.Tensor:
+def pack_wino_weight(w_packed: torch.Tensor, c_in_ld: int, n_tail: int = 0, c_out16: int = 0) -> torch.Tensor:
     """Winograd F(2x2,3x3) form of a packed 3x3 weight ([c_out_pad, 9 * c_in_ld], tap-major K as pack_conv_weight lays
     it out): U = G g G^T per (output, input) channel, computed in fp64 and rounded once, in the B-fragment order
-    conv_wino_kernel loads: float index (((((xi * nchunks + chunk) * n_ct + ct) * 4 + g) * 64 + lh * 32 + li) * 4 + q
-    = U[xi][n = 32 ct + li][k = 32 chunk + 8 g + 4 lh + q].  ``n_tail`` > 0: the last 4 of the c_in_ld input channels are
-    the planar tail operand (bts_conv_desc.tail_planes): U covers the c_in_ld - 4 buffer channels only (whole chunks) --
-    the kernel adds the tail's products directly from the packed fp32 weights."""
+    conv_wino_kernel loads.  Default (32-wide channel tiles, v_mfma_f32_32x32x2_f32): float index
+    (((((xi * nchunks + chunk) * n_ct + ct) * 4 + g) * 64 + lh * 32 + li) * 4 + q = U[xi][n = 32 ct + li][k = 32 chunk + 8 g + 4 lh + q].
+    ``c_out16`` > 0 (the 48-wide tile, v_mfma_f32_16x16x4_f32; c_out16 = real output channels, a multiple of 16):
+    (((((xi * nchunks + chunk) * n_ct16 + ct) * 2 + g) * 64 + l) * 4 + q = U[xi][n = 16 ct + (l & 15)][k = 32 chunk + 16 g + 4 (l >> 4) + q].
+    ``n_tail`` > 0: the last 4 of the c_in_ld input channels are the planar tail operand (bts_conv_desc.tail_planes): U
+    covers the c_in_ld - 4 buffer channels only (whole chunks) -- the kernel adds the tail's products directly from the
+    packed fp32 weights."""
     _need(w_packed, "pack_wino_weight")
     cop = w_packed.shape[0]
     c_main = c_in_ld - (4 if n_tail else 0)
@@ -594,11 +597,15 @@ def pack_wino_weight(w_packed: torch.Tensor, c_in_ld: int, n_tail: int = 0) -> t
         raise BtsHipError("pack_wino_weight: needs a 3x3 weight whose buffer channels are whole 32-channel chunks")
     g = w_packed[:, :9 * c_in_ld].reshape(cop, 3, 3, c_in_ld).permute(0, 3, 1, 2).double()     # [n, k, 3, 3]
     g = g[:, :c_main]
-    c_tot = g.shape[1]
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w_packed.device)
-    U = torch.einsum("ia,nkab,jb->nkij", G, g, G).float().reshape(cop, c_tot, 16)               # [n, k, xi = 4 i + j]
-    n_ct, nchunks = cop // 32, c_tot // 32
-    U = U.view(n_ct, 32, nchunks, 4, 2, 4, 16)                                                  # (ct, li, chunk, g, lh, q, xi)
+    U = torch.einsum("ia,nkab,jb->nkij", G, g, G).float().reshape(cop, c_main, 16)              # [n, k, xi = 4 i + j]
+    nchunks = c_main // 32
+    if c_out16:
+        if c_out16 % 16 or c_out16 > cop:
+            raise BtsHipError("pack_wino_weight: c_out16 must be a multiple of 16 within the packed rows")
+        U = U[:c_out16].reshape(c_out16 // 16, 16, nchunks, 2, 4, 4, 16)                        # (ct, col, chunk, g, kq, q, xi)
+        return U.permute(6, 2, 0, 3, 4, 1, 5).contiguous().view(-1)                              # (xi, chunk, ct, g, kq, col, q): lane = 16 kq + col
+    U = U.view(cop // 32, 32, nchunks, 4, 2, 4, 16)                                             # (ct, li, chunk, g, lh, q, xi)
     return U.permute(6, 2, 0, 3, 4, 1, 5).contiguous().view(-1)                                  # (xi, chunk, ct, g, lh, li, q)
 
 
@@ -669,14 +676,6 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
     keep = []
     d.n_bundles = n_bundles if n_bundles > 1 else 0
     d.fill_frames, d.precision = current_launch_config()
-    if (_WINO and d.precision == 0 and ksize == 3 and stride == 1 and dil == 1 and pad == 1 and up == 1 and not subpixel
-            and n_bundles <= 1 and (c_in_ld - (4 if n_tail else 0)) % 32 == 0 and c_in_ld > 4 and y_nchw is None):
-        uw = getattr(w_packed, "_bts_wino", None)
-        if uw is None:
-            uw = pack_wino_weight(w_packed, c_in_ld, n_tail)
-            w_packed._bts_wino = uw
-        keep.append(uw)
-        d.w_wino = uw.data_ptr()
     if d.precision == 1 and n_bundles <= 1 and not n_tail:
         # weights pre-split into bf16 planes for the emulated mode's halo-tile kernel (LDS-DMA of plain bytes); made once
         # per packed weight tensor and kept on it
@@ -731,6 +730,21 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         if not splitk_ws.is_contiguous():
             raise BtsHipError("conv_forward: splitk_ws must be contiguous")
         d.splitk_ws, d.splitk_ws_floats = splitk_ws.data_ptr(), splitk_ws.numel()
+    if (_WINO and d.precision == 0 and ksize == 3 and stride == 1 and dil == 1 and pad == 1 and up == 1 and not subpixel
+            and n_bundles <= 1 and (c_in_ld - (4 if n_tail else 0)) % 32 == 0 and c_in_ld > 4 and y_nchw is None):
+        # Winograd-form weights for the fused F(2x2,3x3) kernel: made once per packed weight and kept on it
+        uw = getattr(w_packed, "_bts_wino", None)
+        if uw is None:
+            # which channel tile the library will use for this layer (its own decision on the COMPLETE descriptor, asked
+            # once per weight: the two packings differ): 48 -> the 16x16x4 tile
+            d.w_wino = w_packed.data_ptr()
+            bm_, bn_, kind_ = C.c_int(0), C.c_int(0), C.c_int(0)
+            _lib.load_real().bts_conv_plan_f32(C.byref(d), C.byref(bm_), C.byref(bn_), C.byref(kind_))
+            # (bn is choose_tile's pure function of c_out, whatever kernel family this particular launch ends up on)
+            uw = pack_wino_weight(w_packed, c_in_ld, n_tail, c_out16=d.c_out if bn_.value == 48 else 0)
+            w_packed._bts_wino = uw
+        keep.append(uw)
+        d.w_wino = uw.data_ptr()
     cin = c_in_real if c_in_real is not None else c_in_ld
     npix_out = B * H * W
     if n_bundles > 1:                                      # algorithmic FLOPs of the grouped conv are passed in c_in_real

@@ -820,7 +820,7 @@ def test_fill_frames_16_block3_on_wide_and_halo_kernels_frame_independent_cpu_pa
                 if r[1] in b3:
                     b3[r[1]].add(r[0])
             assert b3["enc_b3_1x1"] == {"conv1x1_kernel<192,2>", "conv1x1_kernel<192,4>"}, b3
-            assert b3["enc_b3_3x3"] == {"conv_wino_kernel<64>"}, b3      # (BTS_CONV_WINO=0: conv_halo_kernel<48,k3,nhwc,w8>)
+            assert b3["enc_b3_3x3"] == {"conv_wino_kernel<48>"}, b3      # (BTS_CONV_WINO=0: conv_halo_kernel<48,k3,nhwc,w8>)
             one15 = m(img[15:16].cuda(), foc[15:16].cuda())
             for a, b, c in zip(one0, one15, full):
                 assert torch.equal(a[0], c[0]) and torch.equal(b[0], c[15]), "a frame depends on its batch under fill_frames=16"

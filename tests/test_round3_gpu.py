@@ -384,7 +384,7 @@ def test_winograd_kernel_vs_fp64_and_direct(cin, cout, shape, pre):
     if os.environ.get("BTS_CONV_WINO", "1") in ("", "0"):
         pytest.skip("direct kernels forced by BTS_CONV_WINO=0")
     kern, err_wino, y = _wino_case(cin, cout, shape, pre)
-    assert kern == "conv_wino_kernel<%d>" % (128 if cout >= 128 else 64), kern
+    assert kern == "conv_wino_kernel<%d>" % (128 if cout >= 128 else (48 if cout == 48 else 64)), kern      # 48: the 16x16x4-MFMA tile
     # the direct kernel on the same case, in a child process (the knob is read once per process)
     code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_round3_gpu as R; "
             "k, e, y = R._wino_case(%d, %d, %r, %r); assert not k.startswith('conv_wino'), k; torch.save((e, y), sys.argv[1])"
