@@ -55,7 +55,8 @@ def main():
         sub = up == 2 and k == 3
         wp, cop, kp = ops.pack_upconv_subpixel(wt) if sub else ops.pack_conv_weight(wt)
         y = torch.empty(B * h * up * w * up, cout, device="cuda")
-        run = lambda: ops.conv_forward(x, B, h, w, wp, cout, k, dil=dil, up=up, act=ops.ACT_ELU, y2d=y, subpixel=sub)
+        pre = (torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.1) if name.endswith(".1x1") else None   # DenseNet bottleneck: norm1 + relu on the way in
+        run = lambda: ops.conv_forward(x, B, h, w, wp, cout, k, dil=dil, up=up, act=ops.ACT_ELU, y2d=y, subpixel=sub, pre=pre, pre_relu=pre is not None)
         with ops.launch_config(fill_frames=a.fill_frames, precision=a.precision):
             run()
             torch.cuda.synchronize()
