@@ -17,11 +17,11 @@ SYMBOLS = (
     "bts_reduc_fwd_f32", "bts_conv_fwd_f32", "bts_nchw_to_nhwc_f32", "bts_nhwc_to_nchw_f32",
     "bts_pack_planes_f32", "bts_get_depth_f32", "bts_conv_plan_f32", "bts_conv_plan_ksteps_f32", "bts_maxpool3x3s2_nhwc_f32", "bts_bn_relu_avgpool2_nhwc_f32",
     "bts_conv_wgrad_f32", "bts_bn_train_ws_floats", "bts_bn_train_stats_f32", "bts_bn_apply_nhwc_f32", "bts_bn_train_bwd_f32",
-    "bts_pack_weights_blocks", "bts_pack_weights_f32", "bts_eval_ws_doubles", "bts_eval_depth_metrics_f32",
+    "bts_pack_weights_blocks", "bts_pack_weights_f32", "bts_pack_wino_floats", "bts_pack_wino_f32", "bts_eval_ws_doubles", "bts_eval_depth_metrics_f32",
     "bts_reduc_lpg_fwd_f32", "bts_plan_run", "bts_upconv_combine_f32",
 )
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class ConvDesc(C.Structure):
@@ -149,6 +149,10 @@ def load_real():
     lib.bts_pack_weights_blocks.argtypes = [l, l]
     lib.bts_pack_weights_f32.restype = i
     lib.bts_pack_weights_f32.argtypes = [vp, i, l, vp]
+    lib.bts_pack_wino_floats.restype = l
+    lib.bts_pack_wino_floats.argtypes = [i, i, i, i]
+    lib.bts_pack_wino_f32.restype = i
+    lib.bts_pack_wino_f32.argtypes = [vp, i, l, i, i, i, vp, vp]
     lib.bts_conv_plan_f32.restype = i
     lib.bts_conv_plan_f32.argtypes = [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.bts_conv_plan_ksteps_f32.restype = i

@@ -383,7 +383,64 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __re
     }
 }
 
+// Winograd F(2x2,3x3) form of a packed 3x3 weight, in conv_wino_kernel's B-fragment order (include/bts_hip.h,
+// bts_pack_wino_f32).  One thread = one output f32x4 (four consecutive k of one (xi, n)): U = G g G^T in fp64, rounded once.
+__global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict__ w, long k_pad, int c_in_ld, int c_main, int n_ct,
+                                                        int mf16, float* __restrict__ out, long total4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int lane = (int)(i & 63);
+    long r = i >> 6;
+    const int gpc = mf16 ? 2 : 4;
+    const int g = (int)(r % gpc); r /= gpc;
+    const int ct = (int)(r % n_ct); r /= n_ct;
+    const int nchunks = c_main / 32;
+    const int chunk = (int)(r % nchunks);
+    const int xi = (int)(r / nchunks);
+    const int n = mf16 ? 16 * ct + (lane & 15) : 32 * ct + (lane & 31);
+    const int k0 = mf16 ? 32 * chunk + 16 * g + 4 * (lane >> 4) : 32 * chunk + 8 * g + 4 * (lane >> 5);
+    const int wi = xi >> 2, wj = xi & 3;
+    // rows of G: {1,0,0}, {.5,.5,.5}, {.5,-.5,.5}, {0,0,1}
+    const double Gi[3] = {wi == 0 ? 1.0 : (wi == 3 ? 0.0 : 0.5), wi == 1 ? 0.5 : (wi == 2 ? -0.5 : 0.0), wi == 3 ? 1.0 : (wi == 0 ? 0.0 : 0.5)};
+    const double Gj[3] = {wj == 0 ? 1.0 : (wj == 3 ? 0.0 : 0.5), wj == 1 ? 0.5 : (wj == 2 ? -0.5 : 0.0), wj == 3 ? 1.0 : (wj == 0 ? 0.0 : 0.5)};
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* src = w + (long)n * k_pad + (k0 + q);
+        double acc = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double row = 0.0;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) row += (double)src[(long)(3 * a + b) * c_in_ld] * Gj[b];
+            acc += Gi[a] * row;
+        }
+        o[q] = (float)acc;
+    }
+    *reinterpret_cast<f32x4*>(out + 4 * i) = o;
+}
+
 }  // namespace
+
+extern "C" long bts_pack_wino_floats(int c_out_pad, int c_in_ld, int n_tail, int c_out16) {
+    const int c_main = c_in_ld - (n_tail > 0 ? 4 : 0);
+    if (c_out_pad <= 0 || (c_out_pad & 31) || c_main <= 0 || (c_main & 31) || c_out16 < 0 || (c_out16 & 15) || c_out16 > c_out_pad) return -1;
+    return 16L * c_main * (c_out16 > 0 ? c_out16 : c_out_pad);
+}
+
+extern "C" int bts_pack_wino_f32(const float* w_packed, int c_out_pad, long k_pad, int c_in_ld, int n_tail, int c_out16,
+                                 float* out, bts_stream_t stream) {
+    const long total = bts_pack_wino_floats(c_out_pad, c_in_ld, n_tail, c_out16);
+    if (!w_packed || !out || total <= 0 || k_pad < 9L * c_in_ld || ((uintptr_t)out & 15)) return BTS_ERR_INVALID;
+    const int c_main = c_in_ld - (n_tail > 0 ? 4 : 0);
+    const int mf16 = c_out16 > 0 ? 1 : 0;
+    const int n_ct = mf16 ? c_out16 / 16 : c_out_pad / 32;
+    const long total4 = total / 4, blocks = (total4 + 255) / 256;
+    if (blocks > 2147483647L) return BTS_ERR_INVALID;
+    hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_packed, k_pad, c_in_ld, c_main,
+                       n_ct, mf16, out, total4);
+    return (int)hipGetLastError();
+}
 
 extern "C" long bts_pack_weights_blocks(long rows_pad, long k_pad) {
     return (rows_pad * k_pad + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK;

@@ -580,8 +580,33 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
 _WINO = os.environ.get("BTS_CONV_WINO", "1").strip() not in ("", "0")      # fused Winograd F(2x2,3x3) for eligible 3x3 layers (0: direct kernels, A/B)
 
 
-def pack_wino_weight(w_packed: torch.Tensor, c_in_ld: int, n_tail: int = 0, c_out16: int = 0) -> torch.Tensor:
-    """Winograd F(2x2,3x3) form of a packed 3x3 weight ([c_out_pad, 9 * c_in_ld], tap-major K as pack_conv_weight lays
+def pack_wino_weight(w_packed: torch.Tensor, c_in_ld: int, n_tail: int = 0, c_out16: int = 0,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Winograd F(2x2,3x3) form of a packed 3x3 weight ([c_out_pad, round_up(9 * c_in_ld, 32)], tap-major K as
+    pack_conv_weight lays it out), in the B-fragment order conv_wino_kernel loads: one launch of bts_pack_wino_f32
+    (include/bts_hip.h documents the layout; pack_wino_weight_reference is the torch statement of the same).  ``out``:
+    refill an existing buffer (the training step re-transforms its weights every iteration)."""
+    _need(w_packed, "pack_wino_weight")
+    cop = w_packed.shape[0]
+    if w_packed.dim() != 2 or not w_packed.is_contiguous() or w_packed.shape[1] != round_up(9 * c_in_ld, 32):
+        raise BtsHipError("pack_wino_weight: needs a packed 3x3 weight [c_out_pad, round_up(9 * c_in_ld, 32)]")
+    lib = _lib.load_real()
+    n = lib.bts_pack_wino_floats(cop, c_in_ld, n_tail, c_out16)
+    if n <= 0:
+        raise BtsHipError("pack_wino_weight: needs a 3x3 weight whose buffer channels are whole 32-channel chunks"
+                          " (and c_out16 a multiple of 16 within the packed rows)")
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=w_packed.device)
+    elif out.numel() != n or not out.is_contiguous() or out.device != w_packed.device:
+        raise BtsHipError("pack_wino_weight: `out` does not fit this weight")
+    with torch.cuda.device(w_packed.device):
+        _lib.check(lib.bts_pack_wino_f32(w_packed.data_ptr(), cop, w_packed.shape[1], c_in_ld, n_tail, c_out16, out.data_ptr(),
+                                         _stream(w_packed)), "bts_pack_wino_f32")
+    return out
+
+
+def pack_wino_weight_reference(w_packed: torch.Tensor, c_in_ld: int, n_tail: int = 0, c_out16: int = 0) -> torch.Tensor:
+    """torch (fp64 einsum) statement of pack_wino_weight, kept as its test oracle.  Winograd F(2x2,3x3) form of a packed 3x3 weight ([c_out_pad, 9 * c_in_ld], tap-major K as pack_conv_weight lays
     it out): U = G g G^T per (output, input) channel, computed in fp64 and rounded once, in the B-fragment order
     conv_wino_kernel loads.  Default (32-wide channel tiles, v_mfma_f32_32x32x2_f32): float index
     (((((xi * nchunks + chunk) * n_ct + ct) * 4 + g) * 64 + lh * 32 + li) * 4 + q = U[xi][n = 32 ct + li][k = 32 chunk + 8 g + 4 lh + q].
@@ -680,9 +705,13 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
         # weights pre-split into bf16 planes for the emulated mode's halo-tile kernel (LDS-DMA of plain bytes); made once
         # per packed weight tensor and kept on it
         ws3 = getattr(w_packed, "_bts_split3", None)
-        if ws3 is None:
-            ws3 = split_bf16x3(w_packed)
-            w_packed._bts_split3 = ws3
+        seq3 = getattr(w_packed, "_bts_pack_seq", 0)       # train.WeightPacker refills packed buffers in place: re-split then
+        if ws3 is None or getattr(w_packed, "_bts_split3_seq", 0) != seq3:
+            if ws3 is None:
+                ws3 = split_bf16x3(w_packed)
+            else:
+                ws3.copy_(split_bf16x3(w_packed))
+            w_packed._bts_split3, w_packed._bts_split3_seq = ws3, seq3
         keep.append(ws3)
         d.w_split = ws3.data_ptr()
     d.n_tail = n_tail
@@ -734,6 +763,10 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
             and n_bundles <= 1 and (c_in_ld - (4 if n_tail else 0)) % 32 == 0 and c_in_ld > 4 and y_nchw is None):
         # Winograd-form weights for the fused F(2x2,3x3) kernel: made once per packed weight and kept on it
         uw = getattr(w_packed, "_bts_wino", None)
+        seq = getattr(w_packed, "_bts_pack_seq", 0)        # bumped by train.WeightPacker whenever it refills this buffer in place
+        if uw is not None and getattr(w_packed, "_bts_wino_seq", 0) != seq:
+            pack_wino_weight(w_packed, c_in_ld, n_tail, c_out16=getattr(w_packed, "_bts_wino_c16", 0), out=uw)
+            w_packed._bts_wino_seq = seq
         if uw is None:
             # which channel tile the library will use for this layer (its own decision on the COMPLETE descriptor, asked
             # once per weight: the two packings differ): 48 -> the 16x16x4 tile
@@ -741,8 +774,9 @@ def conv_forward(x2d: torch.Tensor, B: int, h_in: int, w_in: int, w_packed: torc
             bm_, bn_, kind_ = C.c_int(0), C.c_int(0), C.c_int(0)
             _lib.load_real().bts_conv_plan_f32(C.byref(d), C.byref(bm_), C.byref(bn_), C.byref(kind_))
             # (bn is choose_tile's pure function of c_out, whatever kernel family this particular launch ends up on)
-            uw = pack_wino_weight(w_packed, c_in_ld, n_tail, c_out16=d.c_out if bn_.value == 48 else 0)
-            w_packed._bts_wino = uw
+            w_packed._bts_wino_c16 = d.c_out if bn_.value == 48 else 0
+            uw = pack_wino_weight(w_packed, c_in_ld, n_tail, c_out16=w_packed._bts_wino_c16)
+            w_packed._bts_wino, w_packed._bts_wino_seq = uw, seq
         keep.append(uw)
         d.w_wino = uw.data_ptr()
     cin = c_in_real if c_in_real is not None else c_in_ld

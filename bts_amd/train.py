@@ -145,6 +145,8 @@ class WeightPacker:
         _lib.check(rc, "bts_pack_weights_f32")
         for e in items:
             e["version"] = e["wref"]()._version
+            # derived forms cached on the packed buffer (Winograd U, bf16 planes: ops.conv_forward) are now stale
+            e["dst"]._bts_pack_seq = getattr(e["dst"], "_bts_pack_seq", 0) + 1
 
     def get(self, weight, c_in_ld, mode, groups=1):
         """Packed buffer for ``weight`` (an nn.Parameter or any contiguous OIHW CUDA tensor), current with its values:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BTS_HIP_ABI_VERSION 13
+#define BTS_HIP_ABI_VERSION 14
 
 #define BTS_ERR_INVALID      (-1)   /* bad argument (null pointer, non-positive dim, misalignment) */
 #define BTS_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not built here (e.g. odd upratio)  */
@@ -283,6 +283,21 @@ int bts_conv_wgrad_f32(const bts_conv_wgrad_desc* desc, bts_stream_t stream);
  */
 long bts_pack_weights_blocks(long rows_pad, long k_pad);
 int bts_pack_weights_f32(const void* table, int n_entries, long total_blocks, bts_stream_t stream);
+
+/* Winograd F(2x2,3x3) form of a packed 3x3 weight (bts_conv_desc.w_wino; the reference has no counterpart: its 3x3
+ * convolutions, pytorch/bts.py:83-94 / 183-221 and the DenseNet growth convolutions, go to cuDNN).  `w_packed` is the
+ * [c_out_pad][k_pad] matrix bts_conv_fwd_f32 reads (K tap-major, k = tap * c_in_ld + c).  U = G g G^T per (output, input)
+ * channel, computed in fp64 and rounded once, written in the B-fragment order of the fused Winograd kernel:
+ *   32-wide channel tiles (c_out16 == 0): float ((((xi*nchunks + chunk)*n_ct + ct)*4 + g)*64 + lh*32 + li)*4 + q
+ *       = U[xi][n = 32 ct + li][k = 32 chunk + 8 g + 4 lh + q],  n_ct = c_out_pad / 32;
+ *   16-wide tiles (c_out16 = real output channels, a multiple of 16: the 48-wide DenseNet tile):
+ *       ((((xi*nchunks + chunk)*n_ct + ct)*2 + g)*64 + l)*4 + q = U[xi][n = 16 ct + (l & 15)][k = 32 chunk + 16 g + 4 (l >> 4) + q].
+ * n_tail > 0: the last 4 of the c_in_ld channels are the planar tail operand and are left out (the kernel adds their
+ * products directly).  bts_pack_wino_floats = floats `out` must hold (16-byte aligned), or -1 for an unsupported shape
+ * (buffer channels and c_out_pad must be whole multiples of 32). */
+long bts_pack_wino_floats(int c_out_pad, int c_in_ld, int n_tail, int c_out16);
+int bts_pack_wino_f32(const float* w_packed, int c_out_pad, long k_pad, int c_in_ld, int n_tail, int c_out16,
+                      float* out, bts_stream_t stream);
 
 /* Batch-statistic BatchNorm over NHWC rows [npix][C] (nn.BatchNorm2d in train() mode: pytorch/bts.py:69-76,
  * 182-202 and the DenseNet norm layers), C % 4 == 0, row strides % 4 == 0 and >= C (channel slices work in place).

@@ -409,3 +409,61 @@ def test_winograd_kernel_vs_fp64_and_direct(cin, cout, shape, pre):
         with ops.launch_config(fill_frames=16):
             ops.conv_forward(x1, 1, h, w, wp, cout, 3, act=ops.ACT_ELU, y2d=y1, pre=(ps.cuda(), pb.cuda()) if pre else None, pre_relu=pre)
         assert torch.equal(y1.cpu(), y[(B - 1) * h * w:])
+
+
+@pytest.mark.parametrize("cout,cin_ld,n_tail,c16", [(64, 64, 0, 0), (96, 192, 0, 48), (128, 228, 1, 0), (64, 36, 4, 0)])
+def test_pack_wino_weight_kernel_matches_the_torch_statement(cout, cin_ld, n_tail, c16):
+    """bts_pack_wino_f32 (one launch) against pack_wino_weight_reference (torch, fp64 einsum): both fragment layouts, the
+    planar-tail form (last 4 channels left out).  Both compute U = G g G^T in fp64 and round once; the summation order
+    inside the double sums differs, so a value may land on the other side of a rounding tie: <= 1 ulp, almost all equal."""
+    from bts_amd import ops
+    g = torch.Generator().manual_seed(cout + cin_ld)
+    kp = ops.round_up(9 * cin_ld, 32)
+    wp = torch.zeros((cout, kp))
+    wp[:, :9 * cin_ld] = torch.randn((cout, 9 * cin_ld), generator=g) * 0.1
+    wp = wp.cuda()
+    ref = ops.pack_wino_weight_reference(wp, cin_ld, n_tail, c_out16=c16)
+    got = ops.pack_wino_weight(wp, cin_ld, n_tail, c_out16=c16)
+    assert got.shape == ref.shape
+    assert (got == ref).float().mean().item() > 0.9999
+    assert (got - ref).abs().max().item() <= 1.2e-7 * ref.abs().max().item()
+    again = torch.full_like(got, float("nan"))
+    ops.pack_wino_weight(wp, cin_ld, n_tail, c_out16=c16, out=again)                   # refill in place
+    assert torch.equal(again, got)
+    with pytest.raises(Exception):
+        ops.pack_wino_weight(wp, cin_ld, n_tail, c_out16=c16, out=again[:-4])
+
+
+@fp32_only
+def test_training_step_retransforms_the_winograd_weights():
+    """The training step's packed weights are refilled IN PLACE every iteration (train.WeightPacker); forms derived from them
+    and cached on the packed tensor (the Winograd U of ops.conv_forward) must follow.  Two forwards / input gradients of
+    a Winograd-eligible 3x3 convolution with an optimiser-style in-place weight update in between: both match torch on the
+    weights of THEIR step (a stale U would reproduce the first step's result)."""
+    from bts_amd import ops, train
+    torch.manual_seed(5)
+    B, cin, cout, h, w = 4, 64, 64, 64, 128
+    weight = torch.nn.Parameter((torch.randn(cout, cin, 3, 3) * 0.05).cuda())
+    x = torch.randn(B, cin, h, w).cuda().to(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn(B, cout, h, w).cuda()
+
+    def step():
+        train.begin_step()
+        tr = ops.KernelTrace()
+        ops.set_trace(tr)
+        try:
+            y = train.conv2d(x, weight, padding=1, tag="t")
+            (dx,) = torch.autograd.grad(y, x, gy)
+        finally:
+            ops.set_trace(None)
+        assert any(n.startswith("conv_wino_kernel") for n in tr.summary()), list(tr.summary())
+        yr = torch.nn.functional.conv2d(x.detach().double(), weight.detach().double(), padding=1)
+        dxr = torch.nn.functional.conv_transpose2d(gy.double(), weight.detach().double(), padding=1)
+        return ((y.double() - yr).abs().max() / yr.abs().max()).item(), ((dx.double() - dxr).abs().max() / dxr.abs().max()).item(), y.detach().clone()
+
+    e1, d1, y1 = step()
+    with torch.no_grad():                                   # what a fused optimiser does: new values, same storage
+        weight.mul_(-0.5).add_(0.01)
+    e2, d2, y2 = step()
+    assert max(e1, d1, e2, d2) <= 5e-6, (e1, d1, e2, d2)
+    assert (y2 - y1).abs().max().item() > 1e-2              # the two steps really differ
