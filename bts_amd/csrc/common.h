@@ -14,8 +14,14 @@ __device__ __forceinline__ f32x16 mfma32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }      // nn.ELU(alpha=1)
-__device__ __forceinline__ float sigmoid1(float x) { return 1.f / (1.f + expf(-x)); }   // nn.Sigmoid
+// nn.ELU(alpha=1) and nn.Sigmoid on the hardware exponential (v_exp_f32 behind one multiply) and reciprocal: ~3 and ~5 VALU
+// instructions where expm1f / expf + an IEEE division cost ~35 / ~30.  The decoder applies ELU to every output of every
+// convolution (860 M elements per B=16 step) and 32 times per pixel group inside the reduction chains, so the accurate
+// forms were a measurable share of those kernels' issue slots.  exp(x) - 1 is ATen's own ELU formula; its absolute error
+// (<= 1e-7, relative to an O(1) activation scale) is what matters downstream -- the relative error near x = 0, where
+// expm1f differs, does not survive the next layer's sum.  Parity: the oracle / golden tolerances are unchanged (tests).
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+__device__ __forceinline__ float sigmoid1(float x) { return __frcp_rn(1.f + __expf(-x)); }
 
 // Raise a kernel's dynamic-LDS limit above the 64 KB default.  hipFuncAttributeMaxDynamicSharedMemorySize is a property
 // of (function, DEVICE): a process that drives several GPUs (nn.DataParallel: one Python thread per device,
