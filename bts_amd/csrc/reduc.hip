@@ -407,9 +407,16 @@ extern "C" int bts_reduc_fwd_f32(const float* x, long x_pix_stride, long npix, i
             return launch_reduc<128, 64, false>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
         if (c_in == 64 && c_first_out == 32)       // narrow chains: 16x16x4-MFMA kernel (fragments from pack_reduc_weights)
             return launch_reduc16<64, 32, false, RT2>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
+        // bts_size 256 (bts.py:198-217 with num_features = 256): reduc8x8 64 -> 64.., reduc2x2 32 -> 16.. (reduc4x4 is the 64 -> 32 chain above)
+        if (c_in == 64 && c_first_out == 64)
+            return launch_reduc16<64, 64, false, RT2>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
+        if (c_in == 32 && c_first_out == 16)
+            return launch_reduc16<32, 16, false, RT2>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
     } else {
         if (c_in == 32 && c_first_out == 16)
             return launch_reduc16<32, 16, true, RT1>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
+        if (c_in == 16 && c_first_out == 8)        // bts_size 256: reduc1x1 16 -> 8 -> 1
+            return launch_reduc16<16, 8, true, RT1>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, normalize, out, s);
     }
     return BTS_ERR_UNSUPPORTED;
 }
@@ -441,5 +448,12 @@ extern "C" int bts_reduc_lpg_fwd_f32(const float* x, long x_pix_stride, int B, i
         return launch_reduc<128, 64, false, 4>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, 1, plane4, s, lt);
     if (c_in == 64 && c_first_out == 32 && upratio == 2)
         return launch_reduc16<64, 32, false, RT2, 2>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, 1, plane4, s, lt);
+    // bts_size 256: the three scales on the narrow kernel
+    if (c_in == 64 && c_first_out == 64 && upratio == 8)
+        return launch_reduc16<64, 64, false, RT2, 8>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, 1, plane4, s, lt);
+    if (c_in == 64 && c_first_out == 32 && upratio == 4)
+        return launch_reduc16<64, 32, false, RT2, 4>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, 1, plane4, s, lt);
+    if (c_in == 32 && c_first_out == 16 && upratio == 2)
+        return launch_reduc16<32, 16, false, RT2, 2>(x, x_pix_stride, npix, w_frag, w_frag_floats, max_depth, 1, plane4, s, lt);
     return BTS_ERR_UNSUPPORTED;
 }

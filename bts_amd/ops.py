@@ -223,8 +223,9 @@ def reduc_chain(num_in: int, num_out: int) -> List[Tuple[int, int]]:
 
 
 def reduc_uses_mfma16(c_in: int, c_first_out: int) -> bool:
-    """The narrow chains (2x2: 64->32.., 1x1: 32->16..) run on the 16x16x4-MFMA kernel (csrc/reduc.hip)."""
-    return (c_in, c_first_out) in ((64, 32), (32, 16))
+    """The narrow chains (bts_size 512: 2x2 64->32.., 1x1 32->16..; every chain of bts_size 256) run on the 16x16x4-MFMA kernel
+    (csrc/reduc.hip)."""
+    return (c_in, c_first_out) in ((64, 32), (32, 16), (64, 64), (16, 8))      # the last two: bts_size 256
 
 
 def pack_reduc_weights(weights: Sequence[torch.Tensor]) -> torch.Tensor:

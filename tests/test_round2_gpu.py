@@ -242,12 +242,12 @@ def test_large_lds_tile_after_device_switch():
 # ------------------------------------------------------------------------------------ unsupported configurations
 def test_unsupported_bts_size_fails_loudly():
     """bts.py:198-217 derive every width from params.bts_size; libbts_hip.so builds the reduction chains and get_depth
-    of bts_size 512 only.  Anything else must raise BtsHipError(BTS_ERR_UNSUPPORTED), never compute
+    of bts_size 512 and 256.  Anything else must raise BtsHipError(BTS_ERR_UNSUPPORTED), never compute
     something else."""
     from bts_amd import bts as M, ops
     from bts_amd._lib import BtsHipError
     feat = synth.ENCODER_CHANNELS["densenet121_bts"]
-    dec = M.bts(Params("densenet121_bts", 256, 80.0, "kitti"), feat, 256).eval().cuda()
+    dec = M.bts(Params("densenet121_bts", 128, 80.0, "kitti"), feat, 128).eval().cuda()
     feats, focal = make_inputs("K", 1, 32, 64, 1)
     fe = synth.encoder_features(feat, 1, 32, 64, 1)
     with torch.no_grad(), pytest.raises(BtsHipError, match="not built|UNSUPPORTED|unsupported"):

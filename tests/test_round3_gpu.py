@@ -467,3 +467,26 @@ def test_training_step_retransforms_the_winograd_weights():
     e2, d2, y2 = step()
     assert max(e1, d1, e2, d2) <= 5e-6, (e1, d1, e2, d2)
     assert (y2 - y1).abs().max().item() > 1e-2              # the two steps really differ
+
+
+@pytest.mark.parametrize("cname,B,H,W", [("K", 2, 64, 96), ("N", 1, 96, 128)])
+def test_bts_size_256_decoder_matches_the_oracle(cname, B, H, W):
+    """params.bts_size = 256 (bts.py:198-217 derive every decoder width from it): reduction chains 64->64.. / 64->32.. /
+    32->16.. / 16->8->1 on the narrow (16x16x4 MFMA) kernel, get_depth on 16 channels, every convolution at half width.
+    Whole decoder vs the CPU oracle on the same PCG64 synthetic state, tolerances of the bts_size 512 tests."""
+    from bts_amd import bts as M
+    from parity_util import CONFIGS, check_outputs, make_inputs
+    from oracle import bts_oracle as O
+    enc, md, ds, _, _ = CONFIGS[cname]
+    feat = synth.ENCODER_CHANNELS[enc]
+    state_np = synth.decoder_state(feat, 256, 0)
+    dec = M.bts(Params(enc, 256, md, ds), feat, 256)
+    dec.load_state_dict({k: (torch.tensor(v) if np.ndim(v) == 0 else t(v)) for k, v in state_np.items()}, strict=True)
+    dec = dec.eval().cuda()
+    feats, focal = make_inputs(cname, B, H, W, 11)
+    with torch.no_grad():
+        ref, inter = O.decoder_forward(O.state_from_numpy(state_np), feats, focal, md, ds, want_intermediates=True)
+        got = dec([None] + [f.cuda() for f in feats[1:]], focal.cuda())
+    torch.cuda.synchronize()
+    rep = check_outputs(got, ref, inter, what="bts_size 256 %s" % cname)
+    assert max(v for k, v in rep.items() if k != "iconv1_max_abs") <= 2e-5, rep
