@@ -363,3 +363,15 @@ def test_torch_operator_library_registers_the_hot_path_ops():
     assert ops.torch_ops() is t                               # the default binding of the hot-path operators
     with pytest.raises(ops.BtsHipError):
         ops.lpg_forward(torch.zeros(1, 4, 2, 2), 8)
+
+
+def test_pack_wino_size_query_on_the_host():
+    """bts_pack_wino_floats is pure host arithmetic (no GPU): 16 transform positions x buffer channels x output rows; the
+    planar-tail form leaves the last four channels out; shapes the fused Winograd kernel cannot take return -1."""
+    from bts_amd import _lib
+    lib = _lib.load()
+    assert lib.bts_pack_wino_floats(256, 448, 0, 0) == 16 * 448 * 256            # conv4: 32-wide channel tiles
+    assert lib.bts_pack_wino_floats(64, 192, 0, 48) == 16 * 192 * 48             # DenseNet growth conv: 16-wide tiles, 48 real outputs
+    assert lib.bts_pack_wino_floats(128, 228, 1, 0) == 16 * 224 * 128            # conv3: 224 buffer channels + planar tail
+    for bad in ((256, 450, 0, 0), (250, 448, 0, 0), (64, 192, 0, 40), (64, 192, 0, 80), (64, 36, 0, 0), (0, 64, 0, 0)):
+        assert lib.bts_pack_wino_floats(*bad) == -1, bad
