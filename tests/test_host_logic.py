@@ -375,3 +375,32 @@ def test_pack_wino_size_query_on_the_host():
     assert lib.bts_pack_wino_floats(128, 228, 1, 0) == 16 * 224 * 128            # conv3: 224 buffer channels + planar tail
     for bad in ((256, 450, 0, 0), (250, 448, 0, 0), (64, 192, 0, 40), (64, 192, 0, 80), (64, 36, 0, 0), (0, 64, 0, 0)):
         assert lib.bts_pack_wino_floats(*bad) == -1, bad
+
+
+@pytest.mark.parametrize("h,w,cout,expect_wino", [(44, 152, 256, True), (52, 68, 256, True), (88, 304, 48, True),
+                                                  (26, 34, 256, False), (11, 38, 48, False)])
+def test_winograd_is_chosen_by_per_frame_geometry_only(h, w, cout, expect_wino):
+    """The fused Winograd kernel takes a stride-1 3x3 layer when the caller supplies transformed weights and the map fills at
+    least 0.70 of its 8x16-pixel tile grid (44x152: 0.87, the NYU decoder's 52x68: 0.79; 26x34: 0.58 and 11x38: 0.54 stay on
+    the direct kernels) -- and the answer is the same for every batch size (a frame's bits may not depend on its
+    neighbours).  Host-side query: no GPU work, the pointers are never dereferenced."""
+    import ctypes as C
+    from bts_amd import _lib
+    lib = _lib.load_real()
+    kinds = set()
+    for B in (1, 4, 16):
+        d = _lib.ConvDesc()
+        d.x = d.w = d.y = d.w_wino = 0x1000
+        cin = 192
+        d.x_pix_stride = d.c_in_ld = cin
+        d.k_pad = 9 * cin
+        d.B, d.h_in, d.w_in, d.up = B, h, w, 1
+        d.ksize, d.dil, d.stride, d.pad = 3, 1, 1, 1
+        d.c_out, d.c_out_pad = cout, (cout + 31) // 32 * 32
+        d.y_pix_stride = cout
+        d.fill_frames = 16
+        bm, bn, kind = C.c_int(0), C.c_int(0), C.c_int(0)
+        assert lib.bts_conv_plan_f32(C.byref(d), C.byref(bm), C.byref(bn), C.byref(kind)) == 0
+        kinds.add(kind.value & 15)
+    assert len(kinds) == 1, kinds
+    assert (kinds == {6}) == expect_wino, kinds
